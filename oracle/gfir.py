@@ -1,0 +1,114 @@
+"""ctypes binding of oracle/libgfir_interp.so — the CPU ORACLE that executes GFIR work items.
+
+TEST INFRASTRUCTURE ONLY (tests/, __graft_entry__.smoke(), bench.py cpu_baseline).
+The product package never imports this module.
+"""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libgfir_interp.so")
+
+_lib = None
+
+
+def build(force=False):
+    src = [os.path.join(HERE, f) for f in ("gfir_interp.c", "Makefile")] + [os.path.join(HERE, "..", "include", "gfir.h")]
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in src):
+        subprocess.check_call(["make", "-C", HERE, "-s", "libgfir_interp.so"])
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.gfi_load.restype = ctypes.c_void_p
+        _lib.gfi_load.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+        _lib.gfi_free.argtypes = [ctypes.c_void_p]
+        _lib.gfi_info.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        _lib.gfi_setter_inputs.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        for s in ("f64", "f32"):
+            getattr(_lib, "gfi_run_" + s).argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                      ctypes.c_size_t, ctypes.c_size_t]
+            f = getattr(_lib, "gfi_run_threads_" + s)
+            f.restype = ctypes.c_double
+            f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                          ctypes.c_size_t, ctypes.c_size_t]
+    return _lib
+
+
+class Item:
+    """One work item executed on the CPU exactly as gpu::cpu_context's kernel loop would."""
+
+    def __init__(self, source):
+        if isinstance(source, (bytes, bytearray)):
+            data = bytes(source)
+        else:
+            with open(source, "rb") as f:
+                data = f.read()
+        self.handle = lib().gfi_load(data, len(data))
+        if not self.handle:
+            raise ValueError("not a GFIR work item")
+        info = (ctypes.c_uint32*6)()
+        lib().gfi_info(self.handle, info)
+        self.dtype = "f64" if info[0] == 1 else "f32"
+        self.np_dtype = np.float64 if info[0] == 1 else np.float32
+        self.num_inputs, self.num_outputs, self.num_setters = info[1], info[2], info[3]
+        self.num_tables, self.num_instructions = info[4], info[5]
+        si = (ctypes.c_uint32*max(self.num_setters, 1))()
+        lib().gfi_setter_inputs(self.handle, si)
+        self.setter_inputs = [si[i] for i in range(self.num_setters)]
+
+    def __del__(self):
+        try:
+            lib().gfi_free(self.handle)
+        except Exception:
+            pass
+
+    def _pointers(self, arrays):
+        ptrs = (ctypes.c_void_p*max(len(arrays), 1))()
+        for i, a in enumerate(arrays):
+            assert a.dtype == self.np_dtype and a.flags["C_CONTIGUOUS"]
+            ptrs[i] = a.ctypes.data
+        return ptrs
+
+    def run(self, columns, steps=1, threads=1):
+        """columns: list of num_inputs arrays (updated in place by setters).
+        Returns (list of output arrays, wall seconds)."""
+        assert len(columns) == self.num_inputs
+        n = columns[0].size
+        outs = [np.empty(n, dtype=self.np_dtype) for _ in range(self.num_outputs)]
+        fn = getattr(lib(), "gfi_run_threads_" + self.dtype)
+        secs = fn(self.handle, self._pointers(columns), self._pointers(outs), n, steps, threads)
+        return outs, secs
+
+    def converge(self, columns, tolerance=1.0e-30, max_iterations=1000):
+        """workflow::converge_item::run (workflow.hpp:179-205): repeat the kernel until the
+        max of its last output stalls.  Returns (iterations, last max, outputs)."""
+        def max_kernel():
+            outs, _ = self.run(columns)
+            return float(outs[-1].max()), outs
+
+        big = float(np.finfo(self.np_dtype).max)
+        iterations = 0
+        max_residual, outs = max_kernel()
+        last_max = big
+        off_last_max = big
+        while (abs(max_residual) > abs(tolerance) and abs(last_max - max_residual) > abs(tolerance)
+               and abs(off_last_max - max_residual) > abs(tolerance)):
+            took = iterations < max_iterations
+            iterations += 1
+            if not took:
+                break
+            last_max = max_residual
+            if not iterations % 2:
+                off_last_max = max_residual
+            max_residual, outs = max_kernel()
+        return iterations, max_residual, outs

@@ -1,0 +1,203 @@
+/* ---------------------------------------------------------------------------
+ * gfir_interp.c — CPU ORACLE for GFIR work items (test infrastructure only).
+ *
+ * Executes a serialized graph_framework work item (include/gfir.h) one record
+ * at a time in strict IEEE arithmetic: exactly one operation per reference
+ * node, in the arithmetic the node's compile() method emits —
+ *   add/sub/mul/div  arithmetic.hpp:645-669, :1475, :2516, :3508
+ *   fma              arithmetic.hpp:5079-5127 (one real fma)
+ *   sqrt             math.hpp:166
+ *   pow              math.hpp:1199-1230 (integer exponent = repeated multiply)
+ *   gathers          piecewise.hpp:26-65 (index clamp), :349-437, :1072-1208
+ * followed by the stores of cpu_context::create_kernel_postfix
+ * (cpu_context.hpp:522-580): setters first, then outputs.  It is the CPU
+ * restatement of gpu::cpu_context's serial kernel loop (cpu_context.hpp:487).
+ *
+ * Pinned bit-for-bit against oracle/_ref/gf_ref (the reference's own graph
+ * layer) and through it against SURVEY.md §8(c)'s probe values and
+ * graph_tests/efit_gold.nc; see tests/test_oracle.py.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg load
+ * this.  Built with -ffp-contract=off: no fma except where the graph has one.
+ * ------------------------------------------------------------------------- */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include <pthread.h>
+#include <time.h>
+
+#include "../include/gfir.h"
+
+typedef struct {
+    struct gfir_header header;
+    char *name;
+    struct gfir_instruction *ins;
+    uint32_t *outputs;
+    struct gfir_setter *setters;
+    uint32_t *table_rows, *table_cols;
+    double **tables_f64;
+    float **tables_f32;
+} gfi_item;
+
+#define TAKE(dst, bytes) do { if (pos + (bytes) > len) { gfi_free(item); return NULL; } \
+                              memcpy((dst), data + pos, (bytes)); pos += (bytes); } while (0)
+
+void gfi_free(gfi_item *item) {
+    if (!item) return;
+    if (item->tables_f64) for (uint32_t i = 0; i < item->header.num_tables; i++) free(item->tables_f64[i]);
+    if (item->tables_f32) for (uint32_t i = 0; i < item->header.num_tables; i++) free(item->tables_f32[i]);
+    free(item->tables_f64); free(item->tables_f32);
+    free(item->table_rows); free(item->table_cols);
+    free(item->name); free(item->ins); free(item->outputs); free(item->setters);
+    free(item);
+}
+
+gfi_item *gfi_load(const uint8_t *data, const size_t len) {
+    size_t pos = 0;
+    gfi_item *item = calloc(1, sizeof(gfi_item));
+    TAKE(&item->header, sizeof(struct gfir_header));
+    if (memcmp(item->header.magic, GFIR_MAGIC, 8) != 0) { gfi_free(item); return NULL; }
+    const struct gfir_header *h = &item->header;
+    item->name = calloc(h->name_bytes + 1, 1);
+    TAKE(item->name, h->name_bytes);
+    for (uint32_t i = 0; i < h->num_inputs; i++) {
+        uint32_t bytes;
+        TAKE(&bytes, 4);
+        if (pos + bytes > len) { gfi_free(item); return NULL; }
+        pos += bytes;
+    }
+    item->table_rows = calloc(h->num_tables + 1, sizeof(uint32_t));
+    item->table_cols = calloc(h->num_tables + 1, sizeof(uint32_t));
+    item->tables_f64 = calloc(h->num_tables + 1, sizeof(double *));
+    item->tables_f32 = calloc(h->num_tables + 1, sizeof(float *));
+    for (uint32_t i = 0; i < h->num_tables; i++) {
+        struct gfir_table_header th;
+        TAKE(&th, sizeof(th));
+        const size_t count = (size_t)th.rows*th.cols;
+        item->table_rows[i] = th.rows;
+        item->table_cols[i] = th.cols;
+        item->tables_f64[i] = malloc(count*sizeof(double));
+        item->tables_f32[i] = malloc(count*sizeof(float));
+        TAKE(item->tables_f64[i], count*sizeof(double));
+        for (size_t k = 0; k < count; k++) item->tables_f32[i][k] = (float)item->tables_f64[i][k];
+    }
+    item->ins = malloc(sizeof(struct gfir_instruction)*(h->num_instructions + 1));
+    TAKE(item->ins, sizeof(struct gfir_instruction)*h->num_instructions);
+    item->outputs = malloc(sizeof(uint32_t)*(h->num_outputs + 1));
+    TAKE(item->outputs, sizeof(uint32_t)*h->num_outputs);
+    item->setters = malloc(sizeof(struct gfir_setter)*(h->num_setters + 1));
+    TAKE(item->setters, sizeof(struct gfir_setter)*h->num_setters);
+    return item;
+}
+
+void gfi_info(const gfi_item *item, uint32_t *info6) {
+    info6[0] = item->header.dtype;
+    info6[1] = item->header.num_inputs;
+    info6[2] = item->header.num_outputs;
+    info6[3] = item->header.num_setters;
+    info6[4] = item->header.num_tables;
+    info6[5] = item->header.num_instructions;
+}
+
+/* Which inputs a setter overwrites (info for callers). */
+void gfi_setter_inputs(const gfi_item *item, uint32_t *out) {
+    for (uint32_t i = 0; i < item->header.num_setters; i++) out[i] = item->setters[i].input;
+}
+
+#define DEFINE_RUN(SUFFIX, REAL, TABLES, FMA, SQRT, POW, SIN, COS, ATAN2, EXP, LOG, FMIN, FMAX)          \
+static inline size_t gfi_index_##SUFFIX(const REAL x, const REAL scale, const REAL offset,               \
+                                        const uint32_t length) {                                         \
+    const REAL q = (x - offset)/scale;                                                                   \
+    return (size_t)FMIN(FMAX(q, (REAL)0), (REAL)(length - 1));                                           \
+}                                                                                                        \
+/* Elements [begin, end) of SoA columns; outs[o][i] receive outputs, setters update columns in place. */ \
+void gfi_run_##SUFFIX(const gfi_item *item, REAL **columns, REAL **outs,                                 \
+                      const size_t begin, const size_t end) {                                            \
+    const uint32_t n_ins = item->header.num_instructions;                                                \
+    REAL *r = malloc(sizeof(REAL)*(n_ins + 1));                                                          \
+    for (size_t e = begin; e < end; e++) {                                                               \
+        for (uint32_t i = 0; i < n_ins; i++) {                                                           \
+            const struct gfir_instruction *c = &item->ins[i];                                            \
+            switch (c->op) {                                                                             \
+                case GFIR_CONST: r[i] = (REAL)c->imm[0]; break;                                          \
+                case GFIR_INPUT: r[i] = columns[c->a][e]; break;                                         \
+                case GFIR_ADD:   r[i] = r[c->a] + r[c->b]; break;                                        \
+                case GFIR_SUB:   r[i] = r[c->a] - r[c->b]; break;                                        \
+                case GFIR_MUL:   r[i] = r[c->a]*r[c->b]; break;                                          \
+                case GFIR_DIV:   r[i] = r[c->a]/r[c->b]; break;                                          \
+                case GFIR_FMA:   r[i] = FMA(r[c->a], r[c->b], r[c->c]); break;                           \
+                case GFIR_SQRT:  r[i] = SQRT(r[c->a]); break;                                            \
+                case GFIR_POWI: {                                                                        \
+                    REAL v = r[c->a];                                                                    \
+                    for (uint32_t k = 1; k < c->aux; k++) v = v*r[c->a];                                 \
+                    r[i] = v;                                                                            \
+                    break;                                                                               \
+                }                                                                                        \
+                case GFIR_POW:   r[i] = POW(r[c->a], r[c->b]); break;                                    \
+                case GFIR_SIN:   r[i] = SIN(r[c->a]); break;                                             \
+                case GFIR_COS:   r[i] = COS(r[c->a]); break;                                             \
+                case GFIR_ATAN2: r[i] = ATAN2(r[c->b], r[c->a]); break;                                  \
+                case GFIR_EXP:   r[i] = EXP(r[c->a]); break;                                             \
+                case GFIR_LOG:   r[i] = LOG(r[c->a]); break;                                             \
+                case GFIR_GATHER1:                                                                       \
+                    r[i] = item->TABLES[c->aux][gfi_index_##SUFFIX(r[c->a], (REAL)c->imm[0],             \
+                                                                   (REAL)c->imm[1],                      \
+                                                                   item->table_cols[c->aux])];           \
+                    break;                                                                               \
+                case GFIR_GATHER2:                                                                       \
+                    r[i] = item->TABLES[c->aux][gfi_index_##SUFFIX(r[c->a], (REAL)c->imm[0],             \
+                                                                   (REAL)c->imm[1],                      \
+                                                                   item->table_rows[c->aux])             \
+                                                *item->table_cols[c->aux] +                              \
+                                                gfi_index_##SUFFIX(r[c->b], (REAL)c->imm[2],             \
+                                                                   (REAL)c->imm[3],                      \
+                                                                   item->table_cols[c->aux])];           \
+                    break;                                                                               \
+                default: r[i] = (REAL)NAN;                                                               \
+            }                                                                                            \
+        }                                                                                                \
+        for (uint32_t s = 0; s < item->header.num_setters; s++) {                                        \
+            columns[item->setters[s].input][e] = r[item->setters[s].value];                              \
+        }                                                                                                \
+        for (uint32_t o = 0; o < item->header.num_outputs; o++) {                                        \
+            outs[o][e] = r[item->outputs[o]];                                                            \
+        }                                                                                                \
+    }                                                                                                    \
+    free(r);                                                                                             \
+}                                                                                                        \
+typedef struct {                                                                                         \
+    const gfi_item *item; REAL **columns; REAL **outs; size_t begin, end, steps;                         \
+} gfi_job_##SUFFIX;                                                                                      \
+static void *gfi_worker_##SUFFIX(void *p) {                                                              \
+    gfi_job_##SUFFIX *j = p;                                                                             \
+    for (size_t s = 0; s < j->steps; s++) gfi_run_##SUFFIX(j->item, j->columns, j->outs, j->begin, j->end); \
+    return NULL;                                                                                         \
+}                                                                                                        \
+/* `steps` passes over n elements on `threads` host threads, contiguous shards as the reference splits  \
+   them (graph_benchmark/xrays_bench.cpp:38-51).  Returns wall seconds. */                              \
+double gfi_run_threads_##SUFFIX(const gfi_item *item, REAL **columns, REAL **outs, const size_t n,       \
+                                const size_t steps, size_t threads) {                                    \
+    if (threads < 1) threads = 1;                                                                        \
+    if (threads > n) threads = n ? n : 1;                                                                \
+    pthread_t *ids = malloc(sizeof(pthread_t)*threads);                                                  \
+    gfi_job_##SUFFIX *jobs = malloc(sizeof(gfi_job_##SUFFIX)*threads);                                   \
+    const size_t batch = n/threads, extra = n%threads;                                                   \
+    struct timespec t0, t1;                                                                              \
+    clock_gettime(CLOCK_MONOTONIC, &t0);                                                                 \
+    size_t begin = 0;                                                                                    \
+    for (size_t t = 0; t < threads; t++) {                                                               \
+        const size_t count = batch + (extra > t ? 1 : 0);                                                \
+        jobs[t] = (gfi_job_##SUFFIX){item, columns, outs, begin, begin + count, steps};                  \
+        begin += count;                                                                                  \
+        pthread_create(&ids[t], NULL, gfi_worker_##SUFFIX, &jobs[t]);                                    \
+    }                                                                                                    \
+    for (size_t t = 0; t < threads; t++) pthread_join(ids[t], NULL);                                     \
+    clock_gettime(CLOCK_MONOTONIC, &t1);                                                                 \
+    free(ids); free(jobs);                                                                               \
+    return (double)(t1.tv_sec - t0.tv_sec) + 1.0e-9*(double)(t1.tv_nsec - t0.tv_nsec);                   \
+}
+
+DEFINE_RUN(f64, double, tables_f64, fma, sqrt, pow, sin, cos, atan2, exp, log, fmin, fmax)
+DEFINE_RUN(f32, float, tables_f32, fmaf, sqrtf, powf, sinf, cosf, atan2f, expf, logf, fminf, fmaxf)
