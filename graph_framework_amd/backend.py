@@ -1,0 +1,189 @@
+"""Python mirror of the reference's backend-context interface over libgf_hip.so.
+
+`Context` has the members jit::context forwards to its backend
+(graph_framework/jit.hpp:87-338); `Kernel` is the closure
+create_kernel_call/create_max_call return (cuda_context.hpp:316-576).  All
+computation happens in the HIP library; numpy/torch only carry memory.
+"""
+import ctypes
+import zlib
+
+import numpy as np
+
+from . import _lib
+
+_NP = {_lib.GFIR_F32: np.float32, _lib.GFIR_F64: np.float64}
+
+
+def key_of(name):
+    """Buffer key for a variable name.  The reference keys buffers by leaf_node*
+    (cuda_context.hpp:78-80); hosts without node objects key them by name."""
+    if isinstance(name, int):
+        return name
+    data = name.encode()
+    return (zlib.crc32(data) << 32) | zlib.adler32(data)
+
+
+class GfHipError(RuntimeError):
+    pass
+
+
+class Context:
+    """One device + one stream, as gpu::cuda_context(index) (cuda_context.hpp:137-148)."""
+
+    def __init__(self, index=0, stream=None):
+        self.lib = _lib.load()
+        self.handle = self.lib.gfhip_create_context(int(index), ctypes.c_void_p(stream) if stream else None)
+        if not self.handle:
+            raise GfHipError(self.lib.gfhip_last_error(None).decode())
+        self.index = index
+        self.kernels = []
+        self._keepalive = []
+
+    @staticmethod
+    def max_concurrency():
+        return _lib.load().gfhip_max_concurrency()
+
+    @staticmethod
+    def device_type():
+        return _lib.load().gfhip_device_type().decode()
+
+    def close(self):
+        if self.handle:
+            self.lib.gfhip_destroy_context(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, status):
+        if status:
+            raise GfHipError(self.lib.gfhip_last_error(self.handle).decode())
+
+    def add_kernel(self, gfir, num_rays):
+        """jit::context::add_kernel (jit.hpp:118-194) for a serialized work item."""
+        if not isinstance(gfir, (bytes, bytearray)):
+            with open(gfir, "rb") as f:
+                gfir = f.read()
+        handle = self.lib.gfhip_add_kernel(self.handle, gfir, len(gfir), int(num_rays))
+        if not handle:
+            raise GfHipError(self.lib.gfhip_last_error(self.handle).decode())
+        kernel = Kernel(self, handle, int(num_rays))
+        self.kernels.append(kernel)
+        return kernel
+
+    def compile(self):
+        """jit::context::compile (jit.hpp:238-244)."""
+        self._check(self.lib.gfhip_compile(self.handle))
+
+    def wait(self):
+        self._check(self.lib.gfhip_wait(self.handle))
+
+    def copy_to_device(self, key, host):
+        host = np.ascontiguousarray(host)
+        self._check(self.lib.gfhip_copy_to_device(self.handle, key_of(key), host.ctypes.data))
+
+    def copy_to_host(self, key, host):
+        assert host.flags["C_CONTIGUOUS"]
+        self._check(self.lib.gfhip_copy_to_host(self.handle, key_of(key), host.ctypes.data))
+        return host
+
+    def check_value(self, index, key):
+        value = ctypes.c_double()
+        self._check(self.lib.gfhip_check_value(self.handle, key_of(key), int(index), ctypes.byref(value)))
+        return value.value
+
+    def get_buffer(self, key):
+        """(device pointer, element count) of a buffer."""
+        count = ctypes.c_size_t()
+        pointer = self.lib.gfhip_get_buffer(self.handle, key_of(key), ctypes.byref(count))
+        if not pointer:
+            raise GfHipError(self.lib.gfhip_last_error(self.handle).decode())
+        return pointer, count.value
+
+    def set_buffer(self, key, tensor):
+        """Adopt a contiguous torch CUDA tensor (float32/float64) as the buffer for `key`."""
+        import torch
+        assert tensor.is_cuda and tensor.is_contiguous()
+        dtype = {torch.float32: _lib.GFIR_F32, torch.float64: _lib.GFIR_F64}[tensor.dtype]
+        self._keepalive.append(tensor)
+        self._check(self.lib.gfhip_set_buffer(self.handle, key_of(key), tensor.data_ptr(), tensor.numel(), dtype))
+
+    def enable_timing(self, enable=True):
+        self._check(self.lib.gfhip_enable_timing(self.handle, 1 if enable else 0))
+
+
+class Kernel:
+    def __init__(self, context, handle, num_rays):
+        self.context = context
+        self.lib = context.lib
+        self.handle = handle
+        self.num_rays = num_rays
+
+    def info(self):
+        info = _lib.KernelInfo()
+        self.context._check(self.lib.gfhip_kernel_get_info(self.handle, ctypes.byref(info)))
+        return info
+
+    @property
+    def np_dtype(self):
+        return _NP[self.info().dtype]
+
+    def create_kernel_call(self, input_keys, output_keys, input_init=None):
+        """create_kernel_call (cuda_context.hpp:316-531): bind buffers, allocating and
+        uploading `input_init[i]` (numpy array or None) on first sight of a key."""
+        info = self.info()
+        assert len(input_keys) == info.num_inputs and len(output_keys) == info.num_outputs
+        in_keys = (ctypes.c_uint64*max(len(input_keys), 1))(*[key_of(k) for k in input_keys])
+        out_keys = (ctypes.c_uint64*max(len(output_keys), 1))(*[key_of(k) for k in output_keys])
+        init = (ctypes.c_void_p*max(len(input_keys), 1))()
+        keep = []
+        for i, key in enumerate(input_keys):
+            value = None if input_init is None else input_init[i]
+            if value is not None:
+                value = np.ascontiguousarray(value, dtype=_NP[info.dtype])
+                assert value.size >= self.num_rays
+                keep.append(value)
+                init[i] = value.ctypes.data
+        self.context._check(self.lib.gfhip_create_kernel_call(self.handle, in_keys, init, out_keys))
+
+    def run(self, steps=1):
+        self.context._check(self.lib.gfhip_run(self.handle, int(steps)))
+
+    def run_max(self):
+        value = ctypes.c_double()
+        self.context._check(self.lib.gfhip_run_max(self.handle, ctypes.byref(value)))
+        return value.value
+
+    def converge(self, tolerance=1.0e-30, max_iterations=1000):
+        """workflow::converge_item::run (workflow.hpp:179-205).  Returns (iterations, last max)."""
+        iterations = ctypes.c_size_t()
+        last = ctypes.c_double()
+        self.context._check(self.lib.gfhip_converge(self.handle, float(tolerance), int(max_iterations),
+                                                    ctypes.byref(iterations), ctypes.byref(last)))
+        return iterations.value, last.value
+
+    def timing(self):
+        """(average launch ms, launches) since the last call; needs Context.enable_timing()."""
+        ms = ctypes.c_double()
+        launches = ctypes.c_uint64()
+        self.context._check(self.lib.gfhip_kernel_timing(self.handle, ctypes.byref(ms), ctypes.byref(launches)))
+        return ms.value, launches.value
+
+
+def generate_source(gfir):
+    """HIP source and cache hash of a serialized work item (no device needed)."""
+    lib = _lib.load()
+    if not isinstance(gfir, (bytes, bytearray)):
+        with open(gfir, "rb") as f:
+            gfir = f.read()
+    source_hash = ctypes.c_uint64()
+    text = lib.gfhip_generate_source(gfir, len(gfir), ctypes.byref(source_hash))
+    if not text:
+        raise GfHipError(lib.gfhip_last_error(None).decode())
+    source = ctypes.string_at(text).decode()
+    lib.gfhip_free_string(text)
+    return source, source_hash.value

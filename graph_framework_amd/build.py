@@ -1,0 +1,50 @@
+"""Build steps: libgf_hip.so (hipcc, gfx950) and the pre-built kernel cache.
+
+Everything is built IN-TREE so that it travels with the repository snapshot:
+    graph_framework_amd/libgf_hip.so
+    graph_framework_amd/kernel_cache/<source hash>.hsaco   (one per workload item)
+    graph_framework_amd/kernel_cache/<source hash>.hip     (the generated source, for inspection)
+hipcc cross-compiles gfx950 without a GPU.
+"""
+import glob
+import os
+import subprocess
+
+from . import _lib
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+KERNEL_FLAGS = ["-O3", "-ffp-contract=off", "--offload-arch=gfx950"]
+
+
+def build_library(force=False):
+    csrc = os.path.join(_lib.HERE, "csrc")
+    sources = glob.glob(os.path.join(csrc, "*")) + glob.glob(os.path.join(_lib.HERE, "..", "include", "*.h"))
+    newest = max(os.path.getmtime(s) for s in sources)
+    if force or not os.path.exists(_lib.LIB_PATH) or os.path.getmtime(_lib.LIB_PATH) < newest:
+        subprocess.check_call(["make", "-C", csrc, "-s", "HIPCC=" + HIPCC])
+    return _lib.LIB_PATH
+
+
+def prebuild_kernel(gfir_path, force=False):
+    """Lower one workload item and compile it to a gfx950 code object in the kernel cache."""
+    from . import backend
+    source, source_hash = backend.generate_source(gfir_path)
+    os.makedirs(_lib.CACHE_DIR, exist_ok=True)
+    stem = os.path.join(_lib.CACHE_DIR, "%016x" % source_hash)
+    if force or not os.path.exists(stem + ".hsaco"):
+        with open(stem + ".hip", "w") as f:
+            f.write(source)
+        subprocess.check_call([HIPCC, "--genco"] + KERNEL_FLAGS + ["-o", stem + ".hsaco", stem + ".hip"])
+    return stem + ".hsaco"
+
+
+def prebuild_workloads(force=False):
+    built = []
+    for path in sorted(glob.glob(os.path.join(_lib.WORKLOAD_DIR, "*.gfir"))):
+        built.append(prebuild_kernel(path, force))
+    return built
+
+
+def build_all(force=False):
+    build_library(force)
+    return prebuild_workloads(force)

@@ -1,0 +1,631 @@
+//------------------------------------------------------------------------------
+///  @file gf_hip.cpp
+///  @brief libgf_hip.so: the C ABI of include/gf_hip.h on the HIP runtime.
+///
+///  Host side of the MI355X backend: owns the device buffers (keyed like the
+///  reference's kernel_arguments maps, cuda_context.hpp:78-80), lowers GFIR work
+///  items with codegen.hpp, builds them (cached code objects or hipRTC), packs
+///  and uploads the coefficient tables, launches on one HIP stream per context
+///  and runs the converge loop of workflow.hpp:179-205 around the device max
+///  reduction of reduce.hip.
+//------------------------------------------------------------------------------
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+
+#include <dlfcn.h>
+#include <sys/stat.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <limits>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/gf_hip.h"
+#include "codegen.hpp"
+
+namespace gfhip {
+void launch_max_reduce(const void *in, const size_t n, const bool f64,
+                       unsigned long long *result, const unsigned int num_cus, hipStream_t stream);
+}
+
+namespace {
+
+thread_local std::string creation_error;
+
+struct buffer {
+    void *pointer = nullptr;
+    size_t count = 0;
+    uint32_t dtype = GFIR_F64;
+    bool owned = true;
+};
+
+std::string library_directory() {
+    Dl_info info;
+    if (dladdr(reinterpret_cast<void *> (&gfhip_max_concurrency), &info) && info.dli_fname) {
+        std::string path(info.dli_fname);
+        const size_t slash = path.rfind('/');
+        return slash == std::string::npos ? "." : path.substr(0, slash);
+    }
+    return ".";
+}
+
+bool read_file(const std::string &path, std::vector<char> &data) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    f.seekg(0, std::ios::end);
+    const std::streamoff size = f.tellg();
+    f.seekg(0, std::ios::beg);
+    data.resize(static_cast<size_t> (size));
+    f.read(data.data(), size);
+    return static_cast<bool> (f);
+}
+
+std::string hash_name(const uint64_t hash) {
+    char buf[32];
+    std::snprintf(buf, sizeof(buf), "%016llx", static_cast<unsigned long long> (hash));
+    return buf;
+}
+
+}  // namespace
+
+struct gfhip_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    unsigned int num_cus = 256;
+    std::map<uint64_t, buffer> buffers;
+    std::vector<std::unique_ptr<gfhip_kernel>> kernels;
+    std::string error;
+    unsigned long long *device_scalar = nullptr;
+    unsigned long long *host_scalar = nullptr;     // pinned
+    bool timing = false;
+
+    int fail(const std::string &message) {
+        error = message;
+        return 1;
+    }
+    int check(const hipError_t status, const char *what) {
+        if (status != hipSuccess) {
+            return fail(std::string(what) + ": " + hipGetErrorString(status));
+        }
+        return 0;
+    }
+};
+
+struct gfhip_kernel {
+    gfhip_context *ctx = nullptr;
+    gfhip::item item;
+    gfhip::lowered low;
+    size_t num_rays = 0;
+    hipModule_t module = nullptr;
+    hipFunction_t function = nullptr;
+    bool from_cache = false;
+    std::vector<void *> pack_device;
+    std::vector<uint64_t> input_keys, output_keys;
+    bool bound = false;
+    unsigned int grid = 1;
+    int vgprs = 0, sgprs = 0, lds_static = 0, scratch = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
+};
+
+#define GFHIP_TRY(ctx, call, what) do { if ((ctx)->check((call), (what))) return 1; } while (0)
+
+extern "C" int gfhip_max_concurrency(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) {
+        return 0;
+    }
+    return count;
+}
+
+extern "C" const char *gfhip_device_type(void) {
+    return "HIP GPU";
+}
+
+extern "C" const char *gfhip_last_error(const gfhip_context *ctx) {
+    return ctx ? ctx->error.c_str() : creation_error.c_str();
+}
+
+extern "C" gfhip_context *gfhip_create_context(int index, void *stream) {
+    int count = 0;
+    hipError_t status = hipGetDeviceCount(&count);
+    if (status != hipSuccess || count == 0) {
+        creation_error = "no HIP device available";
+        return nullptr;
+    }
+    if (index < 0 || index >= count) {
+        creation_error = "device index out of range";
+        return nullptr;
+    }
+    std::unique_ptr<gfhip_context> ctx(new gfhip_context);
+    ctx->device = index;
+    if ((status = hipSetDevice(index)) != hipSuccess) {
+        creation_error = std::string("hipSetDevice: ") + hipGetErrorString(status);
+        return nullptr;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, index) == hipSuccess) {
+        ctx->num_cus = static_cast<unsigned int> (prop.multiProcessorCount);
+        const std::string arch(prop.gcnArchName);
+        if (arch.rfind("gfx950", 0) != 0) {
+            creation_error = "libgf_hip is built for gfx950 (MI355X); device is " + arch;
+            return nullptr;
+        }
+    }
+    if (stream) {
+        ctx->stream = static_cast<hipStream_t> (stream);
+    } else {
+        if ((status = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
+            creation_error = std::string("hipStreamCreate: ") + hipGetErrorString(status);
+            return nullptr;
+        }
+        ctx->own_stream = true;
+    }
+    if (hipMalloc(reinterpret_cast<void **> (&ctx->device_scalar), sizeof(unsigned long long)) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void **> (&ctx->host_scalar), sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
+        creation_error = "cannot allocate reduction scalars";
+        return nullptr;
+    }
+    return ctx.release();
+}
+
+static void release_kernel(gfhip_kernel *k) {
+    for (void *p : k->pack_device) {
+        if (p) (void)hipFree(p);
+    }
+    for (auto &e : k->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (auto &e : k->free_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (k->module) (void)hipModuleUnload(k->module);
+}
+
+extern "C" void gfhip_destroy_context(gfhip_context *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &k : ctx->kernels) release_kernel(k.get());
+    for (auto &kv : ctx->buffers) {
+        if (kv.second.owned && kv.second.pointer) (void)hipFree(kv.second.pointer);
+    }
+    if (ctx->device_scalar) (void)hipFree(ctx->device_scalar);
+    if (ctx->host_scalar) (void)hipHostFree(ctx->host_scalar);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" gfhip_kernel *gfhip_add_kernel(gfhip_context *ctx, const void *gfir, size_t bytes, size_t num_rays) {
+    if (!ctx) return nullptr;
+    std::unique_ptr<gfhip_kernel> k(new gfhip_kernel);
+    k->ctx = ctx;
+    k->num_rays = num_rays;
+    if (!k->item.parse(gfir, bytes, ctx->error)) {
+        return nullptr;
+    }
+    k->low = gfhip::lower(k->item);
+    ctx->kernels.push_back(std::move(k));
+    return ctx->kernels.back().get();
+}
+
+extern "C" char *gfhip_generate_source(const void *gfir, size_t bytes, uint64_t *source_hash) {
+    gfhip::item it;
+    std::string error;
+    if (!it.parse(gfir, bytes, error)) {
+        creation_error = error;
+        return nullptr;
+    }
+    const gfhip::lowered low = gfhip::lower(it);
+    if (source_hash) *source_hash = low.hash;
+    char *text = static_cast<char *> (std::malloc(low.source.size() + 1));
+    std::memcpy(text, low.source.c_str(), low.source.size() + 1);
+    return text;
+}
+
+extern "C" void gfhip_free_string(char *text) {
+    std::free(text);
+}
+
+//  Build one kernel: cached code object (by source hash) or hipRTC.
+static int build_kernel(gfhip_context *ctx, gfhip_kernel *k) {
+    const std::string file = hash_name(k->low.hash) + ".hsaco";
+    std::vector<std::string> directories;
+    if (const char *env = std::getenv("GFHIP_CACHE_DIR")) directories.push_back(env);
+    directories.push_back(library_directory() + "/kernel_cache");
+
+    std::vector<char> code;
+    for (auto &d : directories) {
+        if (read_file(d + "/" + file, code)) {
+            k->from_cache = true;
+            break;
+        }
+    }
+
+    if (!k->from_cache) {
+        if (std::getenv("GFHIP_REQUIRE_CACHE")) {
+            return ctx->fail("kernel " + k->item.name + " (" + file + ") not in the kernel cache and GFHIP_REQUIRE_CACHE is set");
+        }
+        hiprtcProgram program;
+        if (hiprtcCreateProgram(&program, k->low.source.c_str(), (k->item.name + ".hip").c_str(), 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
+            return ctx->fail("hiprtcCreateProgram failed");
+        }
+        const char *options[] = {"-O3", "-ffp-contract=off", "--offload-arch=gfx950"};
+        const hiprtcResult result = hiprtcCompileProgram(program, 3, options);
+        if (result != HIPRTC_SUCCESS) {
+            size_t log_size = 0;
+            hiprtcGetProgramLogSize(program, &log_size);
+            std::string log(log_size, '\0');
+            if (log_size) hiprtcGetProgramLog(program, &log[0]);
+            hiprtcDestroyProgram(&program);
+            return ctx->fail("hipRTC failed for " + k->item.name + ": " + log);
+        }
+        size_t size = 0;
+        hiprtcGetCodeSize(program, &size);
+        code.resize(size);
+        hiprtcGetCode(program, code.data());
+        hiprtcDestroyProgram(&program);
+        if (const char *env = std::getenv("GFHIP_CACHE_DIR")) {
+            ::mkdir(env, 0755);
+            std::ofstream f(std::string(env) + "/" + file, std::ios::binary);
+            f.write(code.data(), static_cast<std::streamsize> (code.size()));
+        }
+    }
+
+    GFHIP_TRY(ctx, hipModuleLoadData(&k->module, code.data()), "hipModuleLoadData");
+    GFHIP_TRY(ctx, hipModuleGetFunction(&k->function, k->module, k->low.kernel_name.c_str()), "hipModuleGetFunction");
+    (void)hipFuncGetAttribute(&k->vgprs, HIP_FUNC_ATTRIBUTE_NUM_REGS, k->function);
+    (void)hipFuncGetAttribute(&k->lds_static, HIP_FUNC_ATTRIBUTE_SHARED_SIZE_BYTES, k->function);
+    (void)hipFuncGetAttribute(&k->scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, k->function);
+    if (k->low.lds_bytes > 48*1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *> (k->function),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  static_cast<int> (k->low.lds_bytes));
+    }
+
+//  Pack and upload the tables: [cell][column], padded to the pack stride.
+    const size_t esize = k->item.element_size();
+    k->pack_device.assign(k->low.packs.size(), nullptr);
+    for (size_t p = 0; p < k->low.packs.size(); p++) {
+        const gfhip::pack &pk = k->low.packs[p];
+        const size_t cells = pk.cells();
+        std::vector<unsigned char> host(pk.elements()*esize, 0);
+        for (size_t column = 0; column < pk.tables.size(); column++) {
+            const gfhip::table &t = k->item.tables[pk.tables[column]];
+            for (size_t cell = 0; cell < cells; cell++) {
+                if (esize == 8) {
+                    reinterpret_cast<double *> (host.data())[cell*pk.stride + column] = t.data[cell];
+                } else {
+                    reinterpret_cast<float *> (host.data())[cell*pk.stride + column] = static_cast<float> (t.data[cell]);
+                }
+            }
+        }
+        GFHIP_TRY(ctx, hipMalloc(&k->pack_device[p], host.size()), "hipMalloc(pack)");
+        GFHIP_TRY(ctx, hipMemcpy(k->pack_device[p], host.data(), host.size(), hipMemcpyHostToDevice), "hipMemcpy(pack)");
+    }
+
+//  Launch geometry: one lane per ray; the kernel grid-strides, so cap the grid
+//  at a few waves of workgroups per CU.
+    const size_t block = k->low.block_size;
+    size_t want = (k->num_rays + block - 1)/block;
+    if (want < 1) want = 1;
+    const size_t cap = static_cast<size_t> (ctx->num_cus)*64;
+    k->grid = static_cast<unsigned int> (want < cap ? want : cap);
+    return 0;
+}
+
+extern "C" int gfhip_compile(gfhip_context *ctx) {
+    if (!ctx) return 1;
+    GFHIP_TRY(ctx, hipSetDevice(ctx->device), "hipSetDevice");
+    for (auto &k : ctx->kernels) {
+        if (!k->function) {
+            if (build_kernel(ctx, k.get())) return 1;
+        }
+    }
+    return 0;
+}
+
+static int ensure_buffer(gfhip_context *ctx, const uint64_t key, const size_t count, const uint32_t dtype,
+                         const void *init) {
+    auto found = ctx->buffers.find(key);
+    if (found == ctx->buffers.end()) {
+        buffer b;
+        b.count = count;
+        b.dtype = dtype;
+        const size_t bytes = count*(dtype == GFIR_F32 ? 4 : 8);
+        GFHIP_TRY(ctx, hipMalloc(&b.pointer, bytes ? bytes : 8), "hipMalloc(buffer)");
+        if (init) {
+            GFHIP_TRY(ctx, hipMemcpy(b.pointer, init, bytes, hipMemcpyHostToDevice), "hipMemcpy(init)");
+        } else {
+            GFHIP_TRY(ctx, hipMemsetAsync(b.pointer, 0, bytes, ctx->stream), "hipMemset(buffer)");
+        }
+        ctx->buffers[key] = b;
+        return 0;
+    }
+    if (found->second.count < count) {
+        return ctx->fail("buffer is smaller than the kernel's ensemble size");
+    }
+    if (found->second.dtype != dtype) {
+        return ctx->fail("buffer element type does not match the kernel");
+    }
+    return 0;
+}
+
+extern "C" int gfhip_create_kernel_call(gfhip_kernel *k, const uint64_t *input_keys,
+                                        const void *const *input_init, const uint64_t *output_keys) {
+    if (!k) return 1;
+    gfhip_context *ctx = k->ctx;
+    GFHIP_TRY(ctx, hipSetDevice(ctx->device), "hipSetDevice");
+    const size_t ni = k->item.symbols.size(), no = k->item.outputs.size();
+    k->input_keys.assign(input_keys, input_keys + ni);
+    k->output_keys.assign(output_keys, output_keys + no);
+    for (size_t i = 0; i < ni; i++) {
+        if (ensure_buffer(ctx, input_keys[i], k->num_rays, k->item.dtype, input_init ? input_init[i] : nullptr)) return 1;
+    }
+    for (size_t o = 0; o < no; o++) {
+        if (ensure_buffer(ctx, output_keys[o], k->num_rays, k->item.dtype, nullptr)) return 1;
+    }
+//  The kernel's pointers are __restrict__: written buffers must be distinct.
+    for (size_t o = 0; o < no; o++) {
+        for (size_t i = 0; i < ni; i++) {
+            if (output_keys[o] == input_keys[i]) return ctx->fail("an output buffer aliases an input buffer");
+        }
+        for (size_t p = o + 1; p < no; p++) {
+            if (output_keys[o] == output_keys[p]) return ctx->fail("two outputs share one buffer");
+        }
+    }
+    for (size_t i = 0; i < ni; i++) {
+        for (size_t j = i + 1; j < ni; j++) {
+            if (input_keys[i] == input_keys[j]) return ctx->fail("two inputs share one buffer");
+        }
+    }
+    k->bound = true;
+    return 0;
+}
+
+static int launch(gfhip_kernel *k, const uint32_t steps) {
+    gfhip_context *ctx = k->ctx;
+    if (!k->function) return ctx->fail("kernel has not been compiled (gfhip_compile)");
+    if (!k->bound) return ctx->fail("kernel arguments are not bound (gfhip_create_kernel_call)");
+    if (k->num_rays == 0 || steps == 0) return 0;
+
+    std::vector<void *> pointers;
+    for (auto key : k->input_keys) pointers.push_back(ctx->buffers[key].pointer);
+    for (auto key : k->output_keys) pointers.push_back(ctx->buffers[key].pointer);
+    for (void *p : k->pack_device) pointers.push_back(p);
+    unsigned long long n = k->num_rays;
+    unsigned int step_count = steps;
+    std::vector<void *> params;
+    for (auto &p : pointers) params.push_back(&p);
+    params.push_back(&n);
+    params.push_back(&step_count);
+
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (ctx->timing) {
+        if (!k->free_events.empty()) {
+            ev = k->free_events.back();
+            k->free_events.pop_back();
+        } else {
+            GFHIP_TRY(ctx, hipEventCreate(&ev.first), "hipEventCreate");
+            GFHIP_TRY(ctx, hipEventCreate(&ev.second), "hipEventCreate");
+        }
+        GFHIP_TRY(ctx, hipEventRecord(ev.first, ctx->stream), "hipEventRecord");
+    }
+    GFHIP_TRY(ctx, hipModuleLaunchKernel(k->function, k->grid, 1, 1, k->low.block_size, 1, 1,
+                                         static_cast<unsigned int> (k->low.lds_bytes), ctx->stream,
+                                         params.data(), nullptr), "hipModuleLaunchKernel");
+    if (ctx->timing) {
+        GFHIP_TRY(ctx, hipEventRecord(ev.second, ctx->stream), "hipEventRecord");
+        k->events.push_back(ev);
+    }
+    return 0;
+}
+
+extern "C" int gfhip_run(gfhip_kernel *k, uint32_t steps) {
+    if (!k) return 1;
+    GFHIP_TRY(k->ctx, hipSetDevice(k->ctx->device), "hipSetDevice");
+    return launch(k, steps);
+}
+
+static double decode_ordered(const unsigned long long key, const bool f64) {
+    if (f64) {
+        const unsigned long long bits = (key >> 63) ? (key & 0x7FFFFFFFFFFFFFFFull) : ~key;
+        double v;
+        std::memcpy(&v, &bits, 8);
+        return v;
+    }
+    const unsigned int k32 = static_cast<unsigned int> (key);
+    const unsigned int bits = (k32 >> 31) ? (k32 & 0x7FFFFFFFu) : ~k32;
+    float v;
+    std::memcpy(&v, &bits, 4);
+    return static_cast<double> (v);
+}
+
+extern "C" int gfhip_run_max(gfhip_kernel *k, double *max_value) {
+    if (!k) return 1;
+    gfhip_context *ctx = k->ctx;
+    GFHIP_TRY(ctx, hipSetDevice(ctx->device), "hipSetDevice");
+    if (k->output_keys.empty()) return ctx->fail("converge item has no output to reduce");
+    if (launch(k, 1)) return 1;
+    const buffer &b = ctx->buffers[k->output_keys.back()];
+    GFHIP_TRY(ctx, hipMemsetAsync(ctx->device_scalar, 0, sizeof(unsigned long long), ctx->stream), "hipMemsetAsync");
+    gfhip::launch_max_reduce(b.pointer, k->num_rays, k->item.dtype == GFIR_F64, ctx->device_scalar,
+                             ctx->num_cus, ctx->stream);
+    GFHIP_TRY(ctx, hipGetLastError(), "max_reduce launch");
+    GFHIP_TRY(ctx, hipMemcpyAsync(ctx->host_scalar, ctx->device_scalar, sizeof(unsigned long long),
+                                  hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
+    GFHIP_TRY(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    *max_value = k->num_rays ? decode_ordered(*ctx->host_scalar, k->item.dtype == GFIR_F64)
+                             : -std::numeric_limits<double>::infinity();
+    return 0;
+}
+
+//  workflow::converge_item::run, workflow.hpp:179-205, in the item's own type.
+template<typename T>
+static int converge_loop(gfhip_kernel *k, const double tolerance_, const size_t max_iterations,
+                         size_t *iterations_out, double *last_max) {
+    const T tolerance = static_cast<T> (tolerance_);
+    size_t iterations = 0;
+    double value;
+    if (gfhip_run_max(k, &value)) return 1;
+    T max_residual = static_cast<T> (value);
+    T last = std::numeric_limits<T>::max();
+    T off_last = std::numeric_limits<T>::max();
+    while (std::abs(max_residual) > std::abs(tolerance)            &&
+           std::abs(last - max_residual) > std::abs(tolerance)     &&
+           std::abs(off_last - max_residual) > std::abs(tolerance) &&
+           iterations++ < max_iterations) {
+        last = max_residual;
+        if (!(iterations%2)) {
+            off_last = max_residual;
+        }
+        if (gfhip_run_max(k, &value)) return 1;
+        max_residual = static_cast<T> (value);
+    }
+    if (iterations_out) *iterations_out = iterations;
+    if (last_max) *last_max = static_cast<double> (max_residual);
+    if (iterations > max_iterations) {
+//  Same report as workflow.hpp:197-204.
+        std::fprintf(stderr, "Workitem failed to converge with in given iterations.\nMinimum residual reached: %g\n",
+                     static_cast<double> (max_residual));
+    }
+    return 0;
+}
+
+extern "C" int gfhip_converge(gfhip_kernel *k, double tolerance, size_t max_iterations,
+                              size_t *iterations, double *last_max) {
+    if (!k) return 1;
+    if (k->item.dtype == GFIR_F64) {
+        return converge_loop<double> (k, tolerance, max_iterations, iterations, last_max);
+    }
+    return converge_loop<float> (k, tolerance, max_iterations, iterations, last_max);
+}
+
+extern "C" int gfhip_wait(gfhip_context *ctx) {
+    if (!ctx) return 1;
+    GFHIP_TRY(ctx, hipSetDevice(ctx->device), "hipSetDevice");
+    GFHIP_TRY(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    return 0;
+}
+
+static buffer *find_buffer(gfhip_context *ctx, const uint64_t key) {
+    auto found = ctx->buffers.find(key);
+    if (found == ctx->buffers.end()) {
+        ctx->error = "unknown buffer key";
+        return nullptr;
+    }
+    return &found->second;
+}
+
+extern "C" int gfhip_copy_to_device(gfhip_context *ctx, uint64_t key, const void *host) {
+    if (!ctx) return 1;
+    buffer *b = find_buffer(ctx, key);
+    if (!b) return 1;
+    GFHIP_TRY(ctx, hipSetDevice(ctx->device), "hipSetDevice");
+    GFHIP_TRY(ctx, hipMemcpyAsync(b->pointer, host, b->count*(b->dtype == GFIR_F32 ? 4 : 8),
+                                  hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync(H2D)");
+    GFHIP_TRY(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    return 0;
+}
+
+extern "C" int gfhip_copy_to_host(gfhip_context *ctx, uint64_t key, void *host) {
+    if (!ctx) return 1;
+    buffer *b = find_buffer(ctx, key);
+    if (!b) return 1;
+    GFHIP_TRY(ctx, hipSetDevice(ctx->device), "hipSetDevice");
+    GFHIP_TRY(ctx, hipMemcpyAsync(host, b->pointer, b->count*(b->dtype == GFIR_F32 ? 4 : 8),
+                                  hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync(D2H)");
+    GFHIP_TRY(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    return 0;
+}
+
+extern "C" int gfhip_check_value(gfhip_context *ctx, uint64_t key, size_t index, double *value) {
+    if (!ctx) return 1;
+    buffer *b = find_buffer(ctx, key);
+    if (!b) return 1;
+    if (index >= b->count) return ctx->fail("index out of range");
+    GFHIP_TRY(ctx, hipSetDevice(ctx->device), "hipSetDevice");
+    GFHIP_TRY(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    if (b->dtype == GFIR_F64) {
+        double v;
+        GFHIP_TRY(ctx, hipMemcpy(&v, static_cast<double *> (b->pointer) + index, 8, hipMemcpyDeviceToHost), "hipMemcpy");
+        *value = v;
+    } else {
+        float v;
+        GFHIP_TRY(ctx, hipMemcpy(&v, static_cast<float *> (b->pointer) + index, 4, hipMemcpyDeviceToHost), "hipMemcpy");
+        *value = v;
+    }
+    return 0;
+}
+
+extern "C" void *gfhip_get_buffer(gfhip_context *ctx, uint64_t key, size_t *count) {
+    if (!ctx) return nullptr;
+    buffer *b = find_buffer(ctx, key);
+    if (!b) return nullptr;
+    if (count) *count = b->count;
+    return b->pointer;
+}
+
+extern "C" int gfhip_set_buffer(gfhip_context *ctx, uint64_t key, void *device_pointer, size_t count, uint32_t dtype) {
+    if (!ctx) return 1;
+    if (!device_pointer && count) return ctx->fail("null device pointer");
+    if (dtype != GFIR_F32 && dtype != GFIR_F64) return ctx->fail("bad dtype");
+    auto found = ctx->buffers.find(key);
+    if (found != ctx->buffers.end() && found->second.owned && found->second.pointer) {
+        (void)hipFree(found->second.pointer);
+    }
+    buffer b;
+    b.pointer = device_pointer;
+    b.count = count;
+    b.dtype = dtype;
+    b.owned = false;
+    ctx->buffers[key] = b;
+    return 0;
+}
+
+extern "C" int gfhip_kernel_get_info(const gfhip_kernel *k, struct gfhip_kernel_info *info) {
+    if (!k || !info) return 1;
+    std::memset(info, 0, sizeof(*info));
+    info->dtype = k->item.dtype;
+    info->num_inputs = static_cast<uint32_t> (k->item.symbols.size());
+    info->num_outputs = static_cast<uint32_t> (k->item.outputs.size());
+    info->num_setters = static_cast<uint32_t> (k->item.setters.size());
+    info->num_tables = static_cast<uint32_t> (k->item.tables.size());
+    info->num_instructions = static_cast<uint32_t> (k->item.code.size());
+    info->vgprs = static_cast<uint32_t> (k->vgprs);
+    info->lds_bytes = static_cast<uint32_t> (k->lds_static + k->low.lds_bytes);
+    info->scratch_bytes = static_cast<uint32_t> (k->scratch);
+    info->block_size = k->low.block_size;
+    info->grid_size = k->grid;
+    info->from_cache = k->from_cache ? 1 : 0;
+    info->source_hash = k->low.hash;
+    std::strncpy(info->name, k->low.kernel_name.c_str(), sizeof(info->name) - 1);
+    return 0;
+}
+
+extern "C" int gfhip_enable_timing(gfhip_context *ctx, int enable) {
+    if (!ctx) return 1;
+    ctx->timing = enable != 0;
+    return 0;
+}
+
+extern "C" int gfhip_kernel_timing(gfhip_kernel *k, double *average_ms, uint64_t *launches) {
+    if (!k) return 1;
+    gfhip_context *ctx = k->ctx;
+    GFHIP_TRY(ctx, hipSetDevice(ctx->device), "hipSetDevice");
+    GFHIP_TRY(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    double total = 0.0;
+    for (auto &e : k->events) {
+        float ms = 0.0f;
+        GFHIP_TRY(ctx, hipEventElapsedTime(&ms, e.first, e.second), "hipEventElapsedTime");
+        total += ms;
+        k->free_events.push_back(e);
+    }
+    if (launches) *launches = k->events.size();
+    if (average_ms) *average_ms = k->events.empty() ? 0.0 : total/static_cast<double> (k->events.size());
+    k->events.clear();
+    return 0;
+}

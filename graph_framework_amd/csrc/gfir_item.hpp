@@ -1,0 +1,146 @@
+//------------------------------------------------------------------------------
+///  @file gfir_item.hpp
+///  @brief In-memory form of one GFIR work item (include/gfir.h) and its parser.
+//------------------------------------------------------------------------------
+#ifndef gfir_item_hpp
+#define gfir_item_hpp
+
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/gfir.h"
+
+namespace gfhip {
+
+struct table {
+    uint32_t rows, cols;
+    std::vector<double> data;
+};
+
+struct item {
+    uint32_t dtype = GFIR_F64;
+    std::string name;
+    std::vector<std::string> symbols;       ///< one per input, kernel argument order
+    std::vector<table> tables;
+    std::vector<gfir_instruction> code;
+    std::vector<uint32_t> outputs;
+    std::vector<gfir_setter> setters;
+
+    size_t element_size() const {
+        return dtype == GFIR_F32 ? 4 : 8;
+    }
+
+//------------------------------------------------------------------------------
+///  @brief Parse and validate a serialized work item.
+///
+///  @param[in]  data  Serialized bytes.
+///  @param[in]  bytes Number of bytes.
+///  @param[out] error Reason on failure.
+///  @returns True if the item is well formed.
+//------------------------------------------------------------------------------
+    bool parse(const void *data, const size_t bytes, std::string &error) {
+        const uint8_t *p = static_cast<const uint8_t *> (data);
+        size_t pos = 0;
+        auto take = [&] (void *dst, const size_t n) -> bool {
+            if (pos + n > bytes) {
+                error = "GFIR item is truncated";
+                return false;
+            }
+            std::memcpy(dst, p + pos, n);
+            pos += n;
+            return true;
+        };
+
+        gfir_header h;
+        if (!take(&h, sizeof(h))) return false;
+        if (std::memcmp(h.magic, GFIR_MAGIC, 8) != 0) {
+            error = "not a GFIR item (bad magic)";
+            return false;
+        }
+        if (h.dtype != GFIR_F32 && h.dtype != GFIR_F64) {
+            error = "unsupported GFIR dtype";
+            return false;
+        }
+        dtype = h.dtype;
+
+        std::vector<char> text(h.name_bytes + 1, '\0');
+        if (!take(text.data(), h.name_bytes)) return false;
+        name = text.data();
+
+        symbols.clear();
+        for (uint32_t i = 0; i < h.num_inputs; i++) {
+            uint32_t n;
+            if (!take(&n, 4)) return false;
+            std::vector<char> s(n + 1, '\0');
+            if (!take(s.data(), n)) return false;
+            symbols.push_back(s.data());
+        }
+
+        tables.assign(h.num_tables, table());
+        for (auto &t : tables) {
+            gfir_table_header th;
+            if (!take(&th, sizeof(th))) return false;
+            t.rows = th.rows;
+            t.cols = th.cols;
+            if (t.rows == 0 || t.cols == 0) {
+                error = "empty table in GFIR item";
+                return false;
+            }
+            t.data.resize(static_cast<size_t> (th.rows)*th.cols);
+            if (!take(t.data.data(), sizeof(double)*t.data.size())) return false;
+        }
+
+        code.resize(h.num_instructions);
+        if (!take(code.data(), sizeof(gfir_instruction)*code.size())) return false;
+        outputs.resize(h.num_outputs);
+        if (!take(outputs.data(), sizeof(uint32_t)*outputs.size())) return false;
+        setters.resize(h.num_setters);
+        if (!take(setters.data(), sizeof(gfir_setter)*setters.size())) return false;
+
+//  Validate operand indices: records are in SSA order.
+        for (size_t i = 0; i < code.size(); i++) {
+            const gfir_instruction &c = code[i];
+            auto before = [&] (const uint32_t x) { return x < i; };
+            bool ok = true;
+            switch (c.op) {
+                case GFIR_CONST: break;
+                case GFIR_INPUT: ok = c.a < h.num_inputs; break;
+                case GFIR_ADD: case GFIR_SUB: case GFIR_MUL: case GFIR_DIV:
+                case GFIR_POW: case GFIR_ATAN2:
+                    ok = before(c.a) && before(c.b); break;
+                case GFIR_FMA: ok = before(c.a) && before(c.b) && before(c.c); break;
+                case GFIR_SQRT: case GFIR_SIN: case GFIR_COS: case GFIR_EXP: case GFIR_LOG:
+                    ok = before(c.a); break;
+                case GFIR_POWI: ok = before(c.a) && c.aux >= 1 && c.aux <= 64; break;
+                case GFIR_GATHER1:
+                    ok = before(c.a) && c.aux < h.num_tables && tables[c.aux].rows == 1; break;
+                case GFIR_GATHER2:
+                    ok = before(c.a) && before(c.b) && c.aux < h.num_tables; break;
+                default: ok = false;
+            }
+            if (!ok) {
+                error = "malformed GFIR instruction " + std::to_string(i);
+                return false;
+            }
+        }
+        for (auto o : outputs) {
+            if (o >= code.size()) {
+                error = "GFIR output out of range";
+                return false;
+            }
+        }
+        for (auto &s : setters) {
+            if (s.value >= code.size() || s.input >= h.num_inputs) {
+                error = "GFIR setter out of range";
+                return false;
+            }
+        }
+        return true;
+    }
+};
+
+}  // namespace gfhip
+
+#endif /* gfir_item_hpp */

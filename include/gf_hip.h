@@ -1,0 +1,149 @@
+/* ---------------------------------------------------------------------------
+ * gf_hip.h — C ABI of libgf_hip.so, the MI355X (gfx950) backend for
+ * graph_framework work items.
+ *
+ * This is the drop-in boundary.  Every entry point replaces one member of the
+ * reference's duck-typed backend context (the thing jit::context<T,SAFE_MATH>
+ * forwards to: graph_framework/jit.hpp:63-74, :87-338; models
+ * gpu::cpu_context cpu_context.hpp:82-611 and gpu::cuda_context
+ * cuda_context.hpp:73-1005).  graph_framework_amd/hip_context.hpp is the thin
+ * C++ class with the reference's member names that calls these functions; it
+ * is what a maintainer adds next to cuda_context.hpp.
+ *
+ * The reference hands its backend a work item as generated C++ text plus the
+ * node lists; this backend takes the node DAG itself, serialized as GFIR
+ * (include/gfir.h), and lowers it to a CDNA4 kernel: one wavefront lane per
+ * ray/particle, SoA state, spline coefficient tables re-laid-out AoS per cell
+ * and staged through LDS where they fit.
+ *
+ * Conventions: plain pointers and sizes only.  Functions returning int return
+ * 0 on success, non-zero on failure with a message in gfhip_last_error().
+ * A context is bound to one device and one stream and is not thread safe
+ * (one context per host thread/rank, as in the reference).  Buffers are keyed
+ * by an opaque 64-bit value chosen by the caller (the reference keys them by
+ * leaf_node*, cpu_context.hpp:87-89, cuda_context.hpp:78-80) and are shared by
+ * all kernels of the context.
+ * ------------------------------------------------------------------------- */
+#ifndef GF_HIP_H
+#define GF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gfhip_context gfhip_context;
+typedef struct gfhip_kernel gfhip_kernel;
+
+/* Number of devices = number of host threads/ranks a driver should start.
+ * Replaces  static size_t max_concurrency()   (cuda_context.hpp:121-125, jit.hpp:87). */
+int gfhip_max_concurrency(void);
+
+/* Replaces  static std::string device_type()  (cuda_context.hpp:130-132, jit.hpp:92). */
+const char *gfhip_device_type(void);
+
+/* Bind device `index`.  `stream` is a hipStream_t to launch on, or NULL to
+ * create a private one.  Replaces the context constructor  ctx(const size_t index)
+ * (cuda_context.hpp:137-148, jit.hpp:101).  Returns NULL on failure
+ * (gfhip_last_error(NULL) has the reason). */
+gfhip_context *gfhip_create_context(int index, void *stream);
+
+/* Frees every buffer, module and stream the context owns.
+ * Replaces ~cuda_context (cuda_context.hpp:153-185). */
+void gfhip_destroy_context(gfhip_context *ctx);
+
+/* Message of the last failure on this context (ctx may be NULL for creation errors). */
+const char *gfhip_last_error(const gfhip_context *ctx);
+
+/* Register one work item.  `gfir`/`bytes` is the serialized item (include/gfir.h);
+ * `num_rays` is the ensemble size it runs over.
+ * Replaces jit::context::add_kernel (jit.hpp:118-194) together with the
+ * backend's create_kernel_prefix/create_kernel_postfix
+ * (cuda_context.hpp:713-946, cpu_context.hpp:428-584). */
+gfhip_kernel *gfhip_add_kernel(gfhip_context *ctx, const void *gfir, size_t bytes, size_t num_rays);
+
+/* Lower and build every kernel added so far (pre-built code objects are looked
+ * up by source hash in the kernel cache directories, otherwise hipRTC).
+ * Replaces  void compile(source, names, add_reduction)  (cuda_context.hpp:194-302, jit.hpp:238-244). */
+int gfhip_compile(gfhip_context *ctx);
+
+/* Bind the kernel's arguments to buffers.  input_keys[i] / output_keys[o] name
+ * the buffers; on first sight of a key the buffer is allocated with num_rays
+ * elements and, for inputs with a non-NULL input_init[i], filled from that host
+ * array.  Replaces  create_kernel_call(name, inputs, outputs, state, num_rays, ...)
+ * (cuda_context.hpp:316-531, cpu_context.hpp:233-298). */
+int gfhip_create_kernel_call(gfhip_kernel *kernel,
+                             const uint64_t *input_keys, const void *const *input_init,
+                             const uint64_t *output_keys);
+
+/* Asynchronous launch of the kernel on the context's stream (the closure
+ * create_kernel_call returns in the reference).  `steps` > 1 repeats the item
+ * inside one launch, keeping the state in registers between passes. */
+int gfhip_run(gfhip_kernel *kernel, uint32_t steps);
+
+/* Run the kernel, reduce max over its LAST output buffer on the device,
+ * synchronise and return the scalar.  Replaces  create_max_call(arg, run)
+ * (cuda_context.hpp:540-576, cpu_context.hpp:306-322). */
+int gfhip_run_max(gfhip_kernel *kernel, double *max_value);
+
+/* The host loop of workflow::converge_item::run (workflow.hpp:179-205) around
+ * gfhip_run_max: repeat until |max| <= tol, or max stalls against the previous
+ * or the previous-but-one value, or max_iterations.  Results are identical to
+ * calling gfhip_run_max from that loop. */
+int gfhip_converge(gfhip_kernel *kernel, double tolerance, size_t max_iterations,
+                   size_t *iterations, double *last_max);
+
+/* Drain the stream.  Replaces  void wait()  (cuda_context.hpp:581-584). */
+int gfhip_wait(gfhip_context *ctx);
+
+/* Whole-buffer copies, synchronous on return.  Replace copy_to_device /
+ * copy_to_host (cuda_context.hpp:625-643; callers read host data right after,
+ * dispersion.hpp:1472). */
+int gfhip_copy_to_device(gfhip_context *ctx, uint64_t key, const void *host);
+int gfhip_copy_to_host(gfhip_context *ctx, uint64_t key, void *host);
+
+/* Read one element after draining the stream.  Replaces  T check_value(index, node)
+ * (cuda_context.hpp:602-607). */
+int gfhip_check_value(gfhip_context *ctx, uint64_t key, size_t index, double *value);
+
+/* Device pointer and element count of a buffer (NULL if the key is unknown).
+ * The reference's get_buffer (cuda_context.hpp:650-652) returns the managed
+ * pointer; here it is device memory. */
+void *gfhip_get_buffer(gfhip_context *ctx, uint64_t key, size_t *count);
+
+/* Adopt caller-owned device memory (e.g. a shard of a larger allocation) as the
+ * buffer for `key`; the context will not free it. */
+int gfhip_set_buffer(gfhip_context *ctx, uint64_t key, void *device_pointer, size_t count, uint32_t dtype);
+
+/* Introspection used by hosts, tests and the benchmark. */
+struct gfhip_kernel_info {
+    uint32_t dtype;                 /* enum gfir_dtype */
+    uint32_t num_inputs, num_outputs, num_setters, num_tables, num_instructions;
+    uint32_t vgprs, agprs, sgprs, lds_bytes, scratch_bytes;   /* from the code object, after compile */
+    uint32_t block_size, grid_size; /* launch geometry for num_rays */
+    uint32_t from_cache;            /* 1 if the code object came from the kernel cache */
+    uint32_t reserved;
+    uint64_t source_hash;
+    char     name[64];
+};
+int gfhip_kernel_get_info(const gfhip_kernel *kernel, struct gfhip_kernel_info *info);
+
+/* Lowering without a device: returns the generated HIP source of one item in a
+ * malloc'ed, NUL-terminated string (free with gfhip_free_string) and its hash.
+ * Used by __graft_entry__.build() to pre-build code objects with hipcc. */
+char *gfhip_generate_source(const void *gfir, size_t bytes, uint64_t *source_hash);
+void gfhip_free_string(char *text);
+
+/* Average duration in milliseconds of the launches of `kernel` recorded since
+ * the last call (HIP events on the context's stream around every launch when
+ * timing is enabled).  Used by bench.py for the roofline line. */
+int gfhip_enable_timing(gfhip_context *ctx, int enable);
+int gfhip_kernel_timing(gfhip_kernel *kernel, double *average_ms, uint64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* GF_HIP_H */
