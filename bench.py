@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: ray-steps/s of the xrays_bench cold-plasma RK4 `solver_kernel`.
+
+Workload (BASELINE.json configs[1]): graph_benchmark/xrays_bench.cpp:53-102 — every ray
+omega=500, x=2.5, kx=-600 -> Newton, dt=1e-3, cold_plasma on the EFIT equilibrium of
+graph_tests/efit.nc, fp64 — with 1e6 rays PER GPU (weak scaling).  A "step" is one launch of
+`solver_kernel` over the rank's rays (solver_interface::step, solver.hpp:382).  Setup, the
+Newton init and kernel builds are outside the timed region, as in the reference
+(xrays_bench.cpp:88-102); inputs are resident in HBM when the timed region starts.  The
+reference's timed region also contains the final sync_host (8 D2H copies); that PCIe-inclusive
+rate is reported separately as "value_with_sync_host" and is never `value`.
+
+    python bench.py --gpus N --steps K --warmup W          (N=1)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N>1)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+BYTES_PER_RAY_STEP_F64 = 128      # read 8 + write 8 (7 setters + residual) x 8 B, SURVEY.md §8(d)
+HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def cpu_baseline(num_rays, steps, threads):
+    """The CPU oracle (oracle/gfir_interp.c: the reference DAG, strict IEEE, one thread per
+    core, contiguous shards) timed on a bounded sample of the same workload."""
+    from oracle import gfir
+    from graph_framework_amd.xrays import STATE, workload
+    state = dict(t=0.0, w=500.0, x=2.5, y=0.0, z=0.0, kx=-600.0, ky=0.0, kz=0.0)
+    columns = [np.full(num_rays, state[k]) for k in STATE]
+    gfir.Item(workload("loss_kernel_kx")).converge(columns)
+    item = gfir.Item(workload("solver_kernel"))
+    _, seconds = item.run(columns, steps=steps, threads=threads)
+    return num_rays*steps/seconds, seconds
+
+
+def main():
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--gpus", type=int, default=1)
+    parser.add_argument("--steps", type=int, default=200)
+    parser.add_argument("--warmup", type=int, default=10)
+    parser.add_argument("--rays-per-gpu", type=int, default=1000000)
+    parser.add_argument("--no-cpu-baseline", action="store_true")
+    args = parser.parse_args()
+
+    import torch
+    from graph_framework_amd import distributed as gfd
+    from graph_framework_amd.xrays import Rk4ColdPlasmaEfit, STATE, workload
+
+    rank, world, local_rank = gfd.init()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+
+    n_local = args.rays_per_gpu
+    total = n_local*world
+
+#  Rank 0 reads the work items (they carry the equilibrium tables); RCCL broadcast to the rest.
+    items = {}
+    for name in ("loss_kernel_kx", "solver_kernel"):
+        data = b""
+        if rank == 0:
+            with open(workload(name), "rb") as f:
+                data = f.read()
+        items[name] = gfd.broadcast_bytes(data, 0)
+
+    state = dict(t=0.0, w=500.0, x=2.5, y=0.0, z=0.0, kx=-600.0, ky=0.0, kz=0.0)
+    solve = Rk4ColdPlasmaEfit({k: np.full(n_local, v) for k, v in state.items()},
+                              index=local_rank, stream=torch.cuda.current_stream().cuda_stream, items=items)
+    solve.init("kx")
+    solve.compile()
+
+    for _ in range(args.warmup):
+        solve.step()
+    solve.work.context.enable_timing(True)
+
+    gfd.barrier()
+    torch.cuda.synchronize()
+    start = time.perf_counter()
+    for _ in range(args.steps):
+        solve.step()
+    torch.cuda.synchronize()
+    gfd.barrier()
+    elapsed = time.perf_counter() - start
+    sync_start = time.perf_counter()
+    host = solve.sync_host()
+    sync_elapsed = time.perf_counter() - sync_start
+
+    elapsed = gfd.max_over_ranks(elapsed)
+    sync_elapsed = gfd.max_over_ranks(sync_elapsed)
+    kernel_ms, launches = solve.solver.kernel.timing()
+    kernel_ms = gfd.max_over_ranks(kernel_ms)
+
+#  Output-cadence collective: all-gather of the trajectory state over xGMI (not in the step loop).
+    gather_seconds = None
+    if world > 1:
+        device_state = torch.from_numpy(host["x"]).cuda()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in STATE:
+            full = gfd.all_gather_shards(torch.from_numpy(host[k]).cuda(), total)
+            assert full.numel() == total
+        torch.cuda.synchronize()
+        gather_seconds = gfd.max_over_ranks(time.perf_counter() - t0)
+        del device_state
+
+    if rank == 0:
+        info = solve.solver.kernel.info()
+        value = total*args.steps/elapsed
+        achieved = n_local*BYTES_PER_RAY_STEP_F64/(kernel_ms*1.0e-3)/1.0e9 if kernel_ms > 0 else 0.0
+        line = {
+            "metric": "ray-steps/sec on xrays_bench cold-plasma; achieved HBM GB/s vs peak",
+            "value": value,
+            "unit": "ray-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1.0e3*elapsed/args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "xrays_bench cold-plasma RK4 solver_kernel on EFIT (efit.nc), identical rays "
+                                   "omega=500 x=2.5 kx=Newton(-600), dt=1e-3, fp64",
+                       "rays_per_gpu": n_local, "total_rays": total, "parallelism": "rays sharded x%d" % world,
+                       "kernel_nodes": int(info.num_instructions), "vgprs": int(info.vgprs),
+                       "lds_bytes": int(info.lds_bytes), "scratch_bytes": int(info.scratch_bytes),
+                       "code_object_from_cache": bool(info.from_cache)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved/HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": info.name.decode(), "kernel_ms": kernel_ms, "launches": int(launches),
+                         "algorithmic_bytes_per_launch": n_local*BYTES_PER_RAY_STEP_F64,
+                         "note": "kernel is FP64-VALU bound at the reference's op count (see DESIGN.md)"},
+            "value_with_sync_host": total*args.steps/(elapsed + sync_elapsed),
+            "newton_iterations": solve.newton_iterations,
+        }
+        if gather_seconds is not None:
+            line["all_gather_seconds"] = gather_seconds
+        if world == 1 and not args.no_cpu_baseline:
+            cores = os.cpu_count() or 1
+            sample_rays, sample_steps = 64*cores, 40
+            rate, seconds = cpu_baseline(sample_rays, sample_steps, cores)
+            line["cpu_baseline"] = {"value": rate, "unit": "ray-steps/s", "cores": cores, "kind": "port",
+                                    "sample": "%d rays x %d RK4 steps of the same solver_kernel DAG, interpreted "
+                                              "in strict IEEE by oracle/gfir_interp.c on %d threads (%.1f s)"
+                                              % (sample_rays, sample_steps, cores, seconds)}
+        print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

@@ -82,6 +82,12 @@ class Context:
     def wait(self):
         self._check(self.lib.gfhip_wait(self.handle))
 
+    def flags(self):
+        """Status bits raised by kernels (bit 0: fast-division window left), after a drain."""
+        value = ctypes.c_uint32()
+        self._check(self.lib.gfhip_get_flags(self.handle, ctypes.byref(value)))
+        return value.value
+
     def copy_to_device(self, key, host):
         host = np.ascontiguousarray(host)
         self._check(self.lib.gfhip_copy_to_device(self.handle, key_of(key), host.ctypes.data))

@@ -42,6 +42,11 @@ def prebuild_workloads(force=False):
     built = []
     for path in sorted(glob.glob(os.path.join(_lib.WORKLOAD_DIR, "*.gfir"))):
         built.append(prebuild_kernel(path, force))
+#  Drop code objects of earlier lowerings (the cache key is the source hash).
+    keep = {os.path.splitext(b)[0] for b in built}
+    for stale in glob.glob(os.path.join(_lib.CACHE_DIR, "*")):
+        if os.path.splitext(stale)[0] not in keep:
+            os.remove(stale)
     return built
 
 

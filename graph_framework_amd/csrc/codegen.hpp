@@ -31,6 +31,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <sstream>
 #include <string>
@@ -65,6 +66,20 @@ struct lowered {
 struct codegen_options {
     size_t lds_budget = 64*1024;        ///< bytes of LDS the staged packs may use per workgroup
     uint32_t block_size = 256;
+    uint32_t waves_per_simd = 0;        ///< second __launch_bounds__ argument (0 = let the compiler decide)
+    bool shared_reciprocal = true;      ///< fp64 divisions by one denominator share its refined reciprocal
+    bool pow_three_halves = true;       ///< fp64 pow(x, 1.5) as a compensated x*sqrt(x)
+
+//  Environment overrides (they change the generated text, hence the cache key).
+    static codegen_options from_environment() {
+        codegen_options o;
+        if (const char *e = std::getenv("GFHIP_DIVISION")) o.shared_reciprocal = std::string(e) != "ieee";
+        if (const char *e = std::getenv("GFHIP_POW")) o.pow_three_halves = std::string(e) != "libm";
+        if (const char *e = std::getenv("GFHIP_WAVES_PER_SIMD")) o.waves_per_simd = static_cast<uint32_t> (std::atoi(e));
+        if (const char *e = std::getenv("GFHIP_BLOCK_SIZE")) o.block_size = static_cast<uint32_t> (std::atoi(e));
+        if (const char *e = std::getenv("GFHIP_LDS_BUDGET")) o.lds_budget = static_cast<size_t> (std::atol(e));
+        return o;
+    }
 };
 
 inline uint64_t fnv1a(const std::string &s) {
@@ -84,7 +99,7 @@ inline const char *compile_flags() {
 //------------------------------------------------------------------------------
 ///  @brief Lower one item.
 //------------------------------------------------------------------------------
-inline lowered lower(const item &it, const codegen_options &opt = codegen_options()) {
+inline lowered lower(const item &it, const codegen_options &opt = codegen_options::from_environment()) {
     lowered out;
     const bool f64 = it.dtype == GFIR_F64;
     const char *real = f64 ? "double" : "float";
@@ -159,7 +174,46 @@ inline lowered lower(const item &it, const codegen_options &opt = codegen_option
       << it.code.size() << " nodes, " << it.tables.size() << " tables in " << out.packs.size() << " packs.\n";
     s << "#include <hip/hip_runtime.h>\n";
     s << "typedef " << real << " real;\n";
-    s << "extern \"C\" __global__ void __launch_bounds__(" << out.block_size << ")\n" << out.kernel_name << "(";
+    const bool use_shared = f64 && opt.shared_reciprocal;
+    if (f64) {
+        s << R"(
+// IEEE fp64 division as hipcc lowers it is: scale, r = rcp(d) refined by two Newton steps,
+// q = n*r, e = fma(-d, q, n), q' = fma(e, r, q), un-scale, fix special values.  A work item
+// divides many numerators by few denominators (680 divisions, 82 denominators in the RK4
+// kernel), so the refinement is done once per denominator.  Without the scaling the sequence
+// is the same instruction for instruction, hence bit-identical, while d stays in
+// [2^-500, 2^500]; lanes that leave that window are recomputed with the compiler's division.
+__device__ __forceinline__ double gf_rcp(const double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+__device__ __forceinline__ double gf_div(const double n, const double d, const double r) {
+    const double q = n*r;
+    const double e = __builtin_fma(-d, q, n);
+    return __builtin_amdgcn_div_fixup(__builtin_fma(e, r, q), d, n);
+}
+__device__ __forceinline__ bool gf_in_window(const double d) {
+    const double a = __builtin_fabs(d);
+    return a >= 0x1p-500 && a <= 0x1p+500;
+}
+// pow(x, 1.5) = x*sqrt(x) with the rounding error of the square root carried into the
+// product (s + t ~ sqrt(x) to ~100 bits), i.e. rounded once from the exact value almost
+// always, as glibc's pow is; ocml's pow is within 1 ulp only and costs ~10x more.
+__device__ __forceinline__ double gf_pow_three_halves(const double x) {
+    const double s = __builtin_sqrt(x);
+    const double t = __builtin_fma(-s, s, x)*(0.5*__builtin_amdgcn_rcp(s));
+    const double p = x*s;
+    const double c = __builtin_fma(x, s, -p) + x*t;
+    return (x > 0.0 && x < __builtin_inf()) ? p + c : pow(x, 1.5);
+}
+)";
+    }
+    s << "extern \"C\" __global__ void __launch_bounds__(" << out.block_size;
+    if (opt.waves_per_simd) s << ", " << opt.waves_per_simd;
+    s << ")\n" << out.kernel_name << "(";
     for (size_t i = 0; i < it.symbols.size(); i++) {
         s << (out.input_written[i] ? "" : "const ") << "real *__restrict__ in" << i << ", ";
     }
@@ -169,7 +223,7 @@ inline lowered lower(const item &it, const codegen_options &opt = codegen_option
     for (size_t p = 0; p < out.packs.size(); p++) {
         s << "const real *__restrict__ pack" << p << ", ";
     }
-    s << "const unsigned long long n, const unsigned int steps) {\n";
+    s << "unsigned int *__restrict__ flags, const unsigned long long n, const unsigned int steps) {\n";
 
 //  LDS staging.
     if (lds_used) {
@@ -199,107 +253,164 @@ inline lowered lower(const item &it, const codegen_options &opt = codegen_option
         s << "        real o" << o << " = 0;\n";
     }
     s << "        for (unsigned int step = 0; step < steps; step++) {\n";
-
-//  Index groups.
-    typedef std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, double, double, double, double> group_key;
-    std::map<group_key, std::string> groups;
-    size_t group_count = 0;
-    auto index_expression = [&] (const uint32_t arg, const double scale, const double offset,
-                                 const uint32_t length) -> std::string {
-        std::ostringstream e;
-        e << "static_cast<unsigned int> (__builtin_fmin" << sfx << "(__builtin_fmax" << sfx << "((r" << arg << " - "
-          << literal(offset) << ")/" << literal(scale) << ", " << literal(0.0) << "), "
-          << literal(static_cast<double> (length - 1)) << "))";
-        return e.str();
-    };
-
-    const char *ind = "            ";
-    for (size_t i = 0; i < it.code.size(); i++) {
-        const gfir_instruction &c = it.code[i];
-        switch (c.op) {
-            case GFIR_CONST:
-                s << ind << "const real r" << i << " = " << literal(c.imm[0]) << ";\n";
-                break;
-            case GFIR_INPUT:
-                s << ind << "const real r" << i << " = v" << c.a << ";\n";
-                break;
-            case GFIR_ADD:
-                s << ind << "const real r" << i << " = r" << c.a << " + r" << c.b << ";\n";
-                break;
-            case GFIR_SUB:
-                s << ind << "const real r" << i << " = r" << c.a << " - r" << c.b << ";\n";
-                break;
-            case GFIR_MUL:
-                s << ind << "const real r" << i << " = r" << c.a << "*r" << c.b << ";\n";
-                break;
-            case GFIR_DIV:
-                s << ind << "const real r" << i << " = r" << c.a << "/r" << c.b << ";\n";
-                break;
-            case GFIR_FMA:
-                s << ind << "const real r" << i << " = __builtin_fma" << sfx << "(r" << c.a << ", r" << c.b
-                  << ", r" << c.c << ");\n";
-                break;
-            case GFIR_SQRT:
-                s << ind << "const real r" << i << " = __builtin_sqrt" << sfx << "(r" << c.a << ");\n";
-                break;
-            case GFIR_POWI: {
-                s << ind << "const real r" << i << " = r" << c.a;
-                for (uint32_t k = 1; k < c.aux; k++) s << "*r" << c.a;
-                s << ";\n";
-                break;
-            }
-            case GFIR_POW:
-                s << ind << "const real r" << i << " = pow" << sfx << "(r" << c.a << ", r" << c.b << ");\n";
-                break;
-            case GFIR_SIN:
-                s << ind << "const real r" << i << " = sin" << sfx << "(r" << c.a << ");\n";
-                break;
-            case GFIR_COS:
-                s << ind << "const real r" << i << " = cos" << sfx << "(r" << c.a << ");\n";
-                break;
-            case GFIR_ATAN2:
-                s << ind << "const real r" << i << " = atan2" << sfx << "(r" << c.b << ", r" << c.a << ");\n";
-                break;
-            case GFIR_EXP:
-                s << ind << "const real r" << i << " = exp" << sfx << "(r" << c.a << ");\n";
-                break;
-            case GFIR_LOG:
-                s << ind << "const real r" << i << " = log" << sfx << "(r" << c.a << ");\n";
-                break;
-            case GFIR_GATHER1:
-            case GFIR_GATHER2: {
-                const table &t = it.tables[c.aux];
-                const bool two = c.op == GFIR_GATHER2;
-                const group_key key(c.a, two ? c.b : GFIR_NONE, t.rows, t.cols,
-                                    c.imm[0], c.imm[1], two ? c.imm[2] : 0.0, two ? c.imm[3] : 0.0);
-                auto g = groups.find(key);
-                if (g == groups.end()) {
-                    const std::string name = "g" + std::to_string(group_count++);
-                    const pack &p = out.packs[table_pack[c.aux]];
-                    s << ind << "const unsigned int " << name << " = (";
-                    if (two) {
-                        s << index_expression(c.a, c.imm[0], c.imm[1], t.rows) << "*" << t.cols << "u + "
-                          << index_expression(c.b, c.imm[2], c.imm[3], t.cols);
-                    } else {
-                        s << index_expression(c.a, c.imm[0], c.imm[1], t.cols);
-                    }
-                    s << ")*" << p.stride << "u;\n";
-                    g = groups.insert({key, name}).first;
-                }
-                const uint32_t pi = table_pack[c.aux];
-                s << ind << "const real r" << i << " = " << (out.packs[pi].in_lds ? "lds" : "pack") << pi
-                  << "[" << g->second << " + " << table_column[c.aux] << "u];\n";
-                break;
-            }
-            default:
-                s << ind << "#error unsupported GFIR op\n";
-        }
+    for (size_t k = 0; k < it.setters.size(); k++) {
+        s << "            real sv" << k << ";\n";
     }
     for (size_t o = 0; o < it.outputs.size(); o++) {
-        s << ind << "o" << o << " = r" << it.outputs[o] << ";\n";
+        s << "            real so" << o << ";\n";
     }
-    for (auto &st : it.setters) {
-        s << ind << "v" << st.input << " = r" << st.value << ";\n";
+
+//  The node-for-node body.  `shared` = divisions through a reciprocal shared by all
+//  divisions with the same denominator (see gf_rcp/gf_div in the prelude); otherwise the
+//  compiler's IEEE division.
+    auto emit_body = [&] (const bool shared) {
+        typedef std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, double, double, double, double> group_key;
+        std::map<group_key, std::string> groups;
+        std::map<uint32_t, bool> reciprocal_done;
+        size_t group_count = 0;
+        auto index_expression = [&] (const uint32_t arg, const double scale, const double offset,
+                                     const uint32_t length) -> std::string {
+            std::ostringstream e;
+            e << "static_cast<unsigned int> (__builtin_fmin" << sfx << "(__builtin_fmax" << sfx << "(";
+            if (shared) {
+//  The reciprocal literal is the correctly rounded 1/scale; gf_div's residual step makes
+//  the quotient the correctly rounded (r - offset)/scale.
+                e << "gf_div(r" << arg << " - " << literal(offset) << ", " << literal(scale) << ", "
+                  << literal(f64 ? 1.0/scale : static_cast<double> (1.0f/static_cast<float> (scale))) << ")";
+            } else {
+                e << "(r" << arg << " - " << literal(offset) << ")/" << literal(scale);
+            }
+            e << ", " << literal(0.0) << "), " << literal(static_cast<double> (length - 1)) << "))";
+            return e.str();
+        };
+
+        const char *ind = "                ";
+        for (size_t i = 0; i < it.code.size(); i++) {
+            const gfir_instruction &c = it.code[i];
+            switch (c.op) {
+                case GFIR_CONST:
+                    s << ind << "const real r" << i << " = " << literal(c.imm[0]) << ";\n";
+                    break;
+                case GFIR_INPUT:
+                    s << ind << "const real r" << i << " = v" << c.a << ";\n";
+                    break;
+                case GFIR_ADD:
+                    s << ind << "const real r" << i << " = r" << c.a << " + r" << c.b << ";\n";
+                    break;
+                case GFIR_SUB:
+                    s << ind << "const real r" << i << " = r" << c.a << " - r" << c.b << ";\n";
+                    break;
+                case GFIR_MUL:
+                    s << ind << "const real r" << i << " = r" << c.a << "*r" << c.b << ";\n";
+                    break;
+                case GFIR_DIV:
+                    if (shared) {
+                        if (!reciprocal_done[c.b]) {
+                            reciprocal_done[c.b] = true;
+                            s << ind << "const real q" << c.b << " = gf_rcp(r" << c.b << ");\n";
+                            s << ind << "bad |= !gf_in_window(r" << c.b << ");\n";
+                        }
+                        s << ind << "const real r" << i << " = gf_div(r" << c.a << ", r" << c.b << ", q" << c.b << ");\n";
+                    } else {
+                        s << ind << "const real r" << i << " = r" << c.a << "/r" << c.b << ";\n";
+                    }
+                    break;
+                case GFIR_FMA:
+                    s << ind << "const real r" << i << " = __builtin_fma" << sfx << "(r" << c.a << ", r" << c.b
+                      << ", r" << c.c << ");\n";
+                    break;
+                case GFIR_SQRT:
+                    s << ind << "const real r" << i << " = __builtin_sqrt" << sfx << "(r" << c.a << ");\n";
+                    break;
+                case GFIR_POWI: {
+                    s << ind << "const real r" << i << " = r" << c.a;
+                    for (uint32_t k = 1; k < c.aux; k++) s << "*r" << c.a;
+                    s << ";\n";
+                    break;
+                }
+                case GFIR_POW:
+                    if (f64 && opt.pow_three_halves && it.code[c.b].op == GFIR_CONST && it.code[c.b].imm[0] == 1.5) {
+                        s << ind << "const real r" << i << " = gf_pow_three_halves(r" << c.a << ");\n";
+                    } else {
+                        s << ind << "const real r" << i << " = pow" << sfx << "(r" << c.a << ", r" << c.b << ");\n";
+                    }
+                    break;
+                case GFIR_SIN:
+                    s << ind << "const real r" << i << " = sin" << sfx << "(r" << c.a << ");\n";
+                    break;
+                case GFIR_COS:
+                    s << ind << "const real r" << i << " = cos" << sfx << "(r" << c.a << ");\n";
+                    break;
+                case GFIR_ATAN2:
+                    s << ind << "const real r" << i << " = atan2" << sfx << "(r" << c.b << ", r" << c.a << ");\n";
+                    break;
+                case GFIR_EXP:
+                    s << ind << "const real r" << i << " = exp" << sfx << "(r" << c.a << ");\n";
+                    break;
+                case GFIR_LOG:
+                    s << ind << "const real r" << i << " = log" << sfx << "(r" << c.a << ");\n";
+                    break;
+                case GFIR_GATHER1:
+                case GFIR_GATHER2: {
+                    const table &t = it.tables[c.aux];
+                    const bool two = c.op == GFIR_GATHER2;
+                    const group_key key(c.a, two ? c.b : GFIR_NONE, t.rows, t.cols,
+                                        c.imm[0], c.imm[1], two ? c.imm[2] : 0.0, two ? c.imm[3] : 0.0);
+                    auto g = groups.find(key);
+                    if (g == groups.end()) {
+                        const std::string name = "g" + std::to_string(group_count++);
+                        const pack &p = out.packs[table_pack[c.aux]];
+                        s << ind << "const unsigned int " << name << " = (";
+                        if (two) {
+                            s << index_expression(c.a, c.imm[0], c.imm[1], t.rows) << "*" << t.cols << "u + "
+                              << index_expression(c.b, c.imm[2], c.imm[3], t.cols);
+                        } else {
+                            s << index_expression(c.a, c.imm[0], c.imm[1], t.cols);
+                        }
+                        s << ")*" << p.stride << "u;\n";
+                        g = groups.insert({key, name}).first;
+                    }
+                    const uint32_t pi = table_pack[c.aux];
+                    s << ind << "const real r" << i << " = " << (out.packs[pi].in_lds ? "lds" : "pack") << pi
+                      << "[" << g->second << " + " << table_column[c.aux] << "u];\n";
+                    break;
+                }
+                default:
+                    s << ind << "#error unsupported GFIR op\n";
+            }
+        }
+        for (size_t k = 0; k < it.setters.size(); k++) {
+            s << ind << "sv" << k << " = r" << it.setters[k].value << ";\n";
+        }
+        for (size_t o = 0; o < it.outputs.size(); o++) {
+            s << ind << "so" << o << " = r" << it.outputs[o] << ";\n";
+        }
+    };
+
+    if (use_shared) {
+//  A lane whose denominators leave the window in which the unscaled sequence is the IEEE one
+//  (or whose results are not finite) raises a flag the host reports at the next wait():
+//  results are then not guaranteed bit-identical and the item should be rebuilt with
+//  GFHIP_DIVISION=ieee.  Never observed on the hot-path workloads (|d| spans 1e-30..1e+30).
+        s << "            bool bad = false;\n";
+        s << "            {\n";
+        emit_body(true);
+        s << "                real finite_check = " << literal(0.0) << ";\n";
+        for (size_t k = 0; k < it.setters.size(); k++) s << "                finite_check += sv" << k << ";\n";
+        for (size_t o = 0; o < it.outputs.size(); o++) s << "                finite_check += so" << o << ";\n";
+        s << "                bad |= !__builtin_isfinite(finite_check);\n";
+        s << "            }\n";
+        s << "            if (__builtin_expect(bad, 0)) atomicOr(flags, 1u);\n";
+    } else {
+        s << "            {\n";
+        emit_body(false);
+        s << "            }\n";
+    }
+    for (size_t o = 0; o < it.outputs.size(); o++) {
+        s << "            o" << o << " = so" << o << ";\n";
+    }
+    for (size_t k = 0; k < it.setters.size(); k++) {
+        s << "            v" << it.setters[k].input << " = sv" << k << ";\n";
     }
     s << "        }\n";
 //  Stores: setters first, then outputs (cpu_context.hpp:522-580).

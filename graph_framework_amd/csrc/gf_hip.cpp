@@ -84,6 +84,8 @@ struct gfhip_context {
     std::string error;
     unsigned long long *device_scalar = nullptr;
     unsigned long long *host_scalar = nullptr;     // pinned
+    unsigned int *device_flags = nullptr;          // bit 0: a lane left the fast-division window
+    bool flags_reported = false;
     bool timing = false;
 
     int fail(const std::string &message) {
@@ -168,7 +170,9 @@ extern "C" gfhip_context *gfhip_create_context(int index, void *stream) {
         }
         ctx->own_stream = true;
     }
-    if (hipMalloc(reinterpret_cast<void **> (&ctx->device_scalar), sizeof(unsigned long long)) != hipSuccess ||
+    if (hipMalloc(reinterpret_cast<void **> (&ctx->device_flags), sizeof(unsigned int)) != hipSuccess ||
+        hipMemset(ctx->device_flags, 0, sizeof(unsigned int)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **> (&ctx->device_scalar), sizeof(unsigned long long)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **> (&ctx->host_scalar), sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
         creation_error = "cannot allocate reduction scalars";
         return nullptr;
@@ -194,6 +198,7 @@ extern "C" void gfhip_destroy_context(gfhip_context *ctx) {
         if (kv.second.owned && kv.second.pointer) (void)hipFree(kv.second.pointer);
     }
     if (ctx->device_scalar) (void)hipFree(ctx->device_scalar);
+    if (ctx->device_flags) (void)hipFree(ctx->device_flags);
     if (ctx->host_scalar) (void)hipHostFree(ctx->host_scalar);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -396,6 +401,7 @@ static int launch(gfhip_kernel *k, const uint32_t steps) {
     for (auto key : k->input_keys) pointers.push_back(ctx->buffers[key].pointer);
     for (auto key : k->output_keys) pointers.push_back(ctx->buffers[key].pointer);
     for (void *p : k->pack_device) pointers.push_back(p);
+    pointers.push_back(ctx->device_flags);
     unsigned long long n = k->num_rays;
     unsigned int step_count = steps;
     std::vector<void *> params;
@@ -504,10 +510,32 @@ extern "C" int gfhip_converge(gfhip_kernel *k, double tolerance, size_t max_iter
     return converge_loop<float> (k, tolerance, max_iterations, iterations, last_max);
 }
 
+//  After a drain: did any lane leave the window in which the shared-reciprocal division is
+//  the IEEE one?  Reported once, loudly; the data is still returned.
+static int check_flags(gfhip_context *ctx) {
+    unsigned int flags = 0;
+    GFHIP_TRY(ctx, hipMemcpy(&flags, ctx->device_flags, sizeof(flags), hipMemcpyDeviceToHost), "hipMemcpy(flags)");
+    if ((flags & 1u) && !ctx->flags_reported) {
+        ctx->flags_reported = true;
+        std::fprintf(stderr, "graph_framework_amd: a denominator left [2^-500, 2^500] or a result is not finite; "
+                             "fp64 quotients are no longer guaranteed bit-identical to IEEE division. "
+                             "Rebuild with GFHIP_DIVISION=ieee for the exact sequence.\n");
+    }
+    return 0;
+}
+
 extern "C" int gfhip_wait(gfhip_context *ctx) {
     if (!ctx) return 1;
     GFHIP_TRY(ctx, hipSetDevice(ctx->device), "hipSetDevice");
     GFHIP_TRY(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    return check_flags(ctx);
+}
+
+extern "C" int gfhip_get_flags(gfhip_context *ctx, unsigned int *flags) {
+    if (!ctx || !flags) return 1;
+    GFHIP_TRY(ctx, hipSetDevice(ctx->device), "hipSetDevice");
+    GFHIP_TRY(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    GFHIP_TRY(ctx, hipMemcpy(flags, ctx->device_flags, sizeof(unsigned int), hipMemcpyDeviceToHost), "hipMemcpy(flags)");
     return 0;
 }
 

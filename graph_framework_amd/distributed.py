@@ -1,0 +1,96 @@
+"""Multi-GPU layer: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).
+
+The reference has no inter-device communication at all: each device thread builds its own
+graph, reads the equilibrium file itself and writes its own result file
+(graph_benchmark/xrays_bench.cpp:34-108, graph_driver/xrays.cpp:419-461).  The ensemble
+shards trivially, so the step loop needs NO collective.  Two collectives exist, both outside
+the step loop:
+  * broadcast of the work items (which carry the folded equilibrium coefficient tables,
+    1-2 MB each) from rank 0, so that only one rank touches the file system / front end;
+  * all-gather of the trajectory state (8 SoA arrays) at sync/output cadence.
+Shards are contiguous and sized exactly as the reference sizes its per-thread batches.
+"""
+import os
+
+import numpy as np
+
+from .xrays import shard_bounds
+
+
+def init(backend=None):
+    """Initialise torch.distributed from the torchrun environment.  Returns (rank, world, local_rank)."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+def _device():
+    import torch
+    import torch.distributed as dist
+    if dist.is_initialized() and dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def broadcast_bytes(data, src=0):
+    """Broadcast a bytes object (a serialized work item with its tables) from `src`."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return data
+    device = _device()
+    length = torch.tensor([len(data) if dist.get_rank() == src else 0], dtype=torch.int64, device=device)
+    dist.broadcast(length, src)
+    if dist.get_rank() == src:
+        payload = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(device)
+    else:
+        payload = torch.empty(int(length.item()), dtype=torch.uint8, device=device)
+    dist.broadcast(payload, src)
+    return payload.cpu().numpy().tobytes()
+
+
+def all_gather_shards(local, total):
+    """All-gather contiguous shards of unequal size (reference split) into the full array.
+
+    local: 1-D torch tensor holding this rank's shard; total: ensemble size.
+    Shards are padded to the largest shard for the collective and trimmed afterwards."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local.clone()
+    world = dist.get_world_size()
+    sizes = [shard_bounds(total, world, r)[1] - shard_bounds(total, world, r)[0] for r in range(world)]
+    largest = max(sizes)
+    padded = torch.zeros(largest, dtype=local.dtype, device=local.device)
+    padded[:local.numel()] = local
+    gathered = torch.empty(largest*world, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(gathered, padded)
+    return torch.cat([gathered[r*largest:r*largest + sizes[r]] for r in range(world)])
+
+
+def max_over_ranks(value):
+    """MAX all-reduce of a python float (timing)."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=_device())
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    import torch.distributed as dist
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

@@ -38,9 +38,12 @@ def shard_bounds(total, shards, index):
 class Rk4ColdPlasmaEfit:
     """solver::rk4<dispersion::cold_plasma<T>> on an EFIT equilibrium."""
 
-    def __init__(self, state, dtype="f64", index=0, stream=None, prefix=""):
-        """state: dict of host arrays (or scalars) t,w,x,y,z,kx,ky,kz for this shard."""
+    def __init__(self, state, dtype="f64", index=0, stream=None, prefix="", items=None):
+        """state: dict of host arrays (or scalars) t,w,x,y,z,kx,ky,kz for this shard.
+        items: optional {workload name: GFIR bytes} (e.g. received by broadcast from rank 0);
+        by default the exported workload files are read."""
         self.dtype = dtype
+        self.items = items or {}
         self.np_dtype = _NP[dtype]
         sizes = [np.size(state[k]) for k in STATE if np.ndim(state[k]) > 0]
         self.num_rays = max(sizes) if sizes else 1
@@ -55,6 +58,9 @@ class Rk4ColdPlasmaEfit:
         self.newton_iterations = None
         self.newton_last_max = None
 
+    def _item(self, name):
+        return self.items[name] if name in self.items else workload(name, self.dtype)
+
     def _initial(self):
         return {self.prefix + k: self.host[k] for k in STATE}
 
@@ -63,7 +69,7 @@ class Rk4ColdPlasmaEfit:
         (dispersion.hpp:1452-1475): its own manager in the reference, its own converge item
         here; the solved variable is copied back to the host array."""
         work = self.work
-        item = work.add_converge_item(workload("loss_kernel_" + variable, self.dtype), self.keys,
+        item = work.add_converge_item(self._item("loss_kernel_" + variable), self.keys,
                                       [self.prefix + "newton_residual"], self.num_rays, self._initial(),
                                       tolerance, max_iterations)
         work.context.compile()
@@ -77,7 +83,7 @@ class Rk4ColdPlasmaEfit:
     def compile(self):
         """solver_interface::compile (solver.hpp:303-349): the `solver_kernel` item."""
         work = self.work
-        self.solver = work.add_item(workload("solver_kernel", self.dtype), self.keys, [self.residual_key],
+        self.solver = work.add_item(self._item("solver_kernel"), self.keys, [self.residual_key],
                                     self.num_rays, self._initial())
         work.context.compile()
         self.solver.create_kernel_call()

@@ -98,6 +98,12 @@ int gfhip_converge(gfhip_kernel *kernel, double tolerance, size_t max_iterations
 /* Drain the stream.  Replaces  void wait()  (cuda_context.hpp:581-584). */
 int gfhip_wait(gfhip_context *ctx);
 
+/* Status bits raised by kernels since the context was created (after a drain).
+ * Bit 0: a lane's fp64 denominator left [2^-500, 2^500] (or a result was not finite), so
+ * the shared-reciprocal division is no longer guaranteed bit-identical to IEEE division
+ * for that lane; gfhip_wait() also reports this once on stderr. */
+int gfhip_get_flags(gfhip_context *ctx, unsigned int *flags);
+
 /* Whole-buffer copies, synchronous on return.  Replace copy_to_device /
  * copy_to_host (cuda_context.hpp:625-643; callers read host data right after,
  * dispersion.hpp:1472). */
