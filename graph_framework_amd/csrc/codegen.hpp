@@ -29,10 +29,13 @@
 #ifndef gfhip_codegen_hpp
 #define gfhip_codegen_hpp
 
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <map>
+#include <set>
 #include <sstream>
 #include <string>
 #include <tuple>
@@ -58,6 +61,8 @@ struct lowered {
     std::string kernel_name;
     std::vector<pack> packs;
     std::vector<bool> input_written;    ///< input i is the target of a setter
+    std::vector<int> table_parent;      ///< -1 = stored; else the table it is an exact multiple of
+    std::vector<double> table_factor;
     uint32_t block_size = 256;
     size_t lds_bytes = 0;
     uint64_t hash = 0;
@@ -69,11 +74,13 @@ struct codegen_options {
     uint32_t waves_per_simd = 0;        ///< second __launch_bounds__ argument (0 = let the compiler decide)
     bool shared_reciprocal = true;      ///< fp64 divisions by one denominator share its refined reciprocal
     bool pow_three_halves = true;       ///< fp64 pow(x, 1.5) as a compensated x*sqrt(x)
+    bool compact_tables = true;         ///< store only tables that are not an exact multiple of another
 
 //  Environment overrides (they change the generated text, hence the cache key).
     static codegen_options from_environment() {
         codegen_options o;
         if (const char *e = std::getenv("GFHIP_DIVISION")) o.shared_reciprocal = std::string(e) != "ieee";
+        if (const char *e = std::getenv("GFHIP_COMPACT_TABLES")) o.compact_tables = std::string(e) != "0";
         if (const char *e = std::getenv("GFHIP_POW")) o.pow_three_halves = std::string(e) != "libm";
         if (const char *e = std::getenv("GFHIP_WAVES_PER_SIMD")) o.waves_per_simd = static_cast<uint32_t> (std::atoi(e));
         if (const char *e = std::getenv("GFHIP_BLOCK_SIZE")) o.block_size = static_cast<uint32_t> (std::atoi(e));
@@ -126,7 +133,80 @@ inline lowered lower(const item &it, const codegen_options &opt = codegen_option
         out.input_written[s.input] = true;
     }
 
-//  Packs: one per table shape, columns in table order.
+//  Table compaction.  reduce() folds constants into coefficient tables at graph-build time
+//  (arithmetic.hpp:192-247), so a kernel gathers many tables that are a constant times
+//  another one (45 psi tables, 16 independent).  Where fl(k*parent[c]) == table[c] holds for
+//  EVERY cell (checked here, in the item's precision) the table is not stored: its gather
+//  becomes k*(gather of the parent) — the same bits, one multiply instead of a load, and the
+//  2-D pack of the RK4 kernel shrinks from 360 B to one 128 B line per cell.
+    std::vector<int> parent(it.tables.size(), -1);
+    std::vector<double> factor(it.tables.size(), 1.0);
+    if (opt.compact_tables) {
+        auto derive = [&] (const table &from, const table &to, double &k_out) -> bool {
+            if (from.rows != to.rows || from.cols != to.cols) return false;
+            size_t arg = 0;
+            double best = 0.0;
+            for (size_t c = 0; c < from.data.size(); c++) {
+                if ((from.data[c] == 0.0) != (to.data[c] == 0.0)) return false;
+                if (std::fabs(from.data[c]) > best) { best = std::fabs(from.data[c]); arg = c; }
+            }
+            if (best == 0.0) return false;
+            const double k0 = to.data[arg]/from.data[arg];
+            std::vector<double> candidates = {k0, std::nextafter(k0, 1.0E300), std::nextafter(k0, -1.0E300)};
+            for (int q = 1; q <= 12; q++) {
+                const double p = std::nearbyint(k0*q);
+                if (p != 0.0 && std::fabs(p/q - k0) <= 1.0E-12*std::fabs(k0)) candidates.push_back(p/q);
+            }
+            for (const double k : candidates) {
+                bool exact = true;
+                for (size_t c = 0; c < from.data.size() && exact; c++) {
+                    if (f64) {
+                        exact = k*from.data[c] == to.data[c];
+                    } else {
+                        exact = static_cast<float> (k)*static_cast<float> (from.data[c]) == static_cast<float> (to.data[c]) &&
+                                static_cast<double> (static_cast<float> (k)) == k;
+                    }
+                }
+                if (exact) { k_out = k; return true; }
+            }
+            return false;
+        };
+        for (size_t j = 0; j < it.tables.size(); j++) {
+            for (size_t i = 0; i < it.tables.size(); i++) {
+                if (i == j) continue;
+//  Only parents that are stored (roots) or derive from an earlier-decided table: no cycles.
+                int root = static_cast<int> (i);
+                bool cycle = false;
+                while (parent[root] >= 0) { root = parent[root]; if (root == static_cast<int> (j)) { cycle = true; break; } }
+                if (cycle || (i > j && parent[i] < 0 && false)) continue;
+                if (i > j) continue;    // decided tables only
+                double k;
+                if (derive(it.tables[i], it.tables[j], k)) {
+                    parent[j] = static_cast<int> (i);
+                    factor[j] = k;
+                    break;
+                }
+            }
+        }
+//  Second pass: an earlier root that is an exact multiple of a LATER root (e.g. 3*c, stored
+//  before c) is re-parented to it.
+        for (size_t j = 0; j < it.tables.size(); j++) {
+            if (parent[j] >= 0) continue;
+            for (size_t i = j + 1; i < it.tables.size(); i++) {
+                if (parent[i] >= 0) continue;
+                double k;
+                if (derive(it.tables[i], it.tables[j], k)) {
+                    parent[j] = static_cast<int> (i);
+                    factor[j] = k;
+                    break;
+                }
+            }
+        }
+    }
+    out.table_parent = parent;
+    out.table_factor = factor;
+
+//  Packs: one per table shape, one column per STORED table, in table order.
     std::map<std::pair<uint32_t, uint32_t>, size_t> pack_of_shape;
     std::vector<uint32_t> table_pack(it.tables.size()), table_column(it.tables.size());
     for (size_t t = 0; t < it.tables.size(); t++) {
@@ -141,6 +221,7 @@ inline lowered lower(const item &it, const codegen_options &opt = codegen_option
         }
         pack &p = out.packs[found->second];
         table_pack[t] = static_cast<uint32_t> (found->second);
+        if (parent[t] >= 0) continue;
         table_column[t] = static_cast<uint32_t> (p.tables.size());
         p.tables.push_back(static_cast<uint32_t> (t));
     }
@@ -194,10 +275,6 @@ __device__ __forceinline__ double gf_div(const double n, const double d, const d
     const double q = n*r;
     const double e = __builtin_fma(-d, q, n);
     return __builtin_amdgcn_div_fixup(__builtin_fma(e, r, q), d, n);
-}
-__device__ __forceinline__ bool gf_in_window(const double d) {
-    const double a = __builtin_fabs(d);
-    return a >= 0x1p-500 && a <= 0x1p+500;
 }
 // pow(x, 1.5) = x*sqrt(x) with the rounding error of the square root carried into the
 // product (s + t ~ sqrt(x) to ~100 bits), i.e. rounded once from the exact value almost
@@ -267,6 +344,7 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
         typedef std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, double, double, double, double> group_key;
         std::map<group_key, std::string> groups;
         std::map<uint32_t, bool> reciprocal_done;
+        std::set<std::string> coefficients;
         size_t group_count = 0;
         auto index_expression = [&] (const uint32_t arg, const double scale, const double offset,
                                      const uint32_t length) -> std::string {
@@ -308,7 +386,8 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
                         if (!reciprocal_done[c.b]) {
                             reciprocal_done[c.b] = true;
                             s << ind << "const real q" << c.b << " = gf_rcp(r" << c.b << ");\n";
-                            s << ind << "bad |= !gf_in_window(r" << c.b << ");\n";
+                            s << ind << "dmax = __builtin_fmax(dmax, __builtin_fabs(r" << c.b << "));\n";
+                            s << ind << "dmin = __builtin_fmin(dmin, __builtin_fabs(r" << c.b << "));\n";
                         }
                         s << ind << "const real r" << i << " = gf_div(r" << c.a << ", r" << c.b << ", q" << c.b << ");\n";
                     } else {
@@ -370,9 +449,24 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
                         s << ")*" << p.stride << "u;\n";
                         g = groups.insert({key, name}).first;
                     }
-                    const uint32_t pi = table_pack[c.aux];
-                    s << ind << "const real r" << i << " = " << (out.packs[pi].in_lds ? "lds" : "pack") << pi
-                      << "[" << g->second << " + " << table_column[c.aux] << "u];\n";
+//  Value of table `t` at this group's cell: a load for stored tables, an exact multiple of
+//  the parent's value otherwise; one definition per (group, table).
+                    std::function<std::string(uint32_t)> value_at = [&] (const uint32_t t) -> std::string {
+                        const std::string name = "c" + g->second.substr(1) + "_" + std::to_string(t);
+                        if (coefficients.insert(name).second) {
+                            if (parent[t] >= 0) {
+                                const std::string from = value_at(static_cast<uint32_t> (parent[t]));
+                                s << ind << "const real " << name << " = " << literal(factor[t]) << "*" << from << ";\n";
+                            } else {
+                                const uint32_t pi = table_pack[t];
+                                s << ind << "const real " << name << " = " << (out.packs[pi].in_lds ? "lds" : "pack") << pi
+                                  << "[" << g->second << " + " << table_column[t] << "u];\n";
+                            }
+                        }
+                        return name;
+                    };
+                    const std::string value = value_at(c.aux);
+                    s << ind << "const real r" << i << " = " << value << ";\n";
                     break;
                 }
                 default:
@@ -393,12 +487,13 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
 //  results are then not guaranteed bit-identical and the item should be rebuilt with
 //  GFHIP_DIVISION=ieee.  Never observed on the hot-path workloads (|d| spans 1e-30..1e+30).
         s << "            bool bad = false;\n";
+        s << "            real dmax = 0x1p+0, dmin = 0x1p+0;   // extreme |denominator| of this pass\n";
         s << "            {\n";
         emit_body(true);
         s << "                real finite_check = " << literal(0.0) << ";\n";
         for (size_t k = 0; k < it.setters.size(); k++) s << "                finite_check += sv" << k << ";\n";
         for (size_t o = 0; o < it.outputs.size(); o++) s << "                finite_check += so" << o << ";\n";
-        s << "                bad |= !__builtin_isfinite(finite_check);\n";
+        s << "                bad = !__builtin_isfinite(finite_check) || !(dmin >= 0x1p-500) || !(dmax <= 0x1p+500);\n";
         s << "            }\n";
         s << "            if (__builtin_expect(bad, 0)) atomicOr(flags, 1u);\n";
     } else {

@@ -64,6 +64,13 @@ struct item {
             return false;
         }
         dtype = h.dtype;
+//  Every count is bounded by the bytes that remain, before anything is allocated.
+        if (h.name_bytes > bytes || h.num_inputs > bytes/4 || h.num_tables > bytes/8 ||
+            h.num_instructions > bytes/sizeof(gfir_instruction) || h.num_outputs > bytes/4 ||
+            h.num_setters > bytes/sizeof(gfir_setter)) {
+            error = "GFIR header counts exceed the item size";
+            return false;
+        }
 
         std::vector<char> text(h.name_bytes + 1, '\0');
         if (!take(text.data(), h.name_bytes)) return false;
@@ -73,6 +80,10 @@ struct item {
         for (uint32_t i = 0; i < h.num_inputs; i++) {
             uint32_t n;
             if (!take(&n, 4)) return false;
+            if (n > bytes) {
+                error = "GFIR item is truncated";
+                return false;
+            }
             std::vector<char> s(n + 1, '\0');
             if (!take(s.data(), n)) return false;
             symbols.push_back(s.data());
@@ -86,6 +97,10 @@ struct item {
             t.cols = th.cols;
             if (t.rows == 0 || t.cols == 0) {
                 error = "empty table in GFIR item";
+                return false;
+            }
+            if (static_cast<size_t> (th.rows)*th.cols > bytes/sizeof(double)) {
+                error = "GFIR item is truncated";
                 return false;
             }
             t.data.resize(static_cast<size_t> (th.rows)*th.cols);

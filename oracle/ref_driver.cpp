@@ -28,6 +28,7 @@
 #include <cstring>
 #include <cmath>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 #include <limits>
@@ -762,95 +763,123 @@ static int cmd_trace(const raw_tables &raw, const char *in_path, const char *out
     return 0;
 }
 
-//  korc <in: x y z ux uy uz gamma> <out> <num_steps> <save_every>
 //  graph_korc/xkorc.cpp:29-121 + efit::get_characteristic_field equilibrium.hpp:1585-1615.
+template<typename T>
+struct korc_graphs {
+    efit<T> eq;
+    T b0_value = 0, larmor_value = 0;
+    size_t axis_iterations = 0;
+    T axis_x = 0, axis_z = 0;
+    std::unique_ptr<work_item<T>> axis_newton, bmod, init, step;
+
+    explicit korc_graphs(const raw_tables &raw) : eq(raw) {
+//  get_characteristic_field: two-unknown Newton (step 0.1) to the magnetic axis, then |B|.
+        auto x_axis = graph::variable<T> (1, "x");
+        auto y_axis = graph::variable<T> (1, "y");
+        auto z_axis = graph::variable<T> (1, "z");
+        auto b_axis = eq.get_magnetic_field(x_axis, y_axis, z_axis);
+        auto b_mod = b_axis->length();
+        auto func = (eq.psi_cache - eq.psimin)/eq.dpsi;
+        const T newton_step = static_cast<T> (0.1);
+        axis_newton.reset(new work_item<T> ({x_axis, y_axis, z_axis}, {func*func},
+                                            {{x_axis - newton_step*func/func->df(x_axis), x_axis},
+                                             {z_axis - newton_step*func/func->df(z_axis), z_axis}}));
+        bmod.reset(new work_item<T> ({x_axis, y_axis, z_axis}, {b_mod}, {}));
+        std::vector<std::vector<T>> axis = {{static_cast<T> (1.7)}, {static_cast<T> (0.0)}, {static_cast<T> (0.0)}};
+        T res, last;
+        axis_iterations = converge(*axis_newton, 1, pointers(axis, 0, 3), &res, static_cast<T> (1.0E-30), 1000, &last);
+        bmod->run(1, pointers(axis, 0, 3), {&b0_value});
+        axis_x = axis[0][0];
+        axis_z = axis[2][0];
+
+        auto b0 = graph::constant<T> (b0_value);
+        const T q = 1.602176634E-19;
+        const T me = 9.1093837139E-31;
+        const T c = 299792458.0;
+        auto gryo_period = me/(q*b0);
+        auto larmor_radius = c*gryo_period;
+        larmor_value = larmor_radius->evaluate().at(0);
+
+        auto ux = graph::variable<T> (1, "u_{x}");
+        auto uy = graph::variable<T> (1, "u_{y}");
+        auto uz = graph::variable<T> (1, "u_{z}");
+        auto x = graph::variable<T> (1, "x");
+        auto y = graph::variable<T> (1, "y");
+        auto z = graph::variable<T> (1, "z");
+        auto pos = graph::vector(x, y, z);
+        auto u_vec = graph::vector(ux, uy, uz);
+        auto gamma = graph::variable<T> (1, "\\gamma");
+        auto dt = graph::constant<T> (0.5);
+
+        auto gamma_init = 1.0/graph::sqrt(1.0 - u_vec->dot(u_vec));
+        auto u_init = gamma_init*u_vec;
+        auto b_vec = eq.get_magnetic_field(pos->get_x(), pos->get_y(), pos->get_z())/b0;
+
+        init.reset(new work_item<T> ({ux, uy, uz, gamma}, {},
+                                     {{u_init->get_x(), ux}, {u_init->get_y(), uy}, {u_init->get_z(), uz}, {gamma_init, gamma}}));
+
+        auto u_prime = u_vec - dt*u_vec->cross(b_vec)/(2.0*gamma);
+        auto tau = -0.5*dt*b_vec;
+        auto tau_sq = tau->dot(tau);
+        auto speed_sq = u_prime->dot(u_prime);
+        auto sigma = 1.0 + speed_sq - tau_sq;
+        auto ustar = u_prime->dot(tau);
+        auto gamma_next = graph::sqrt(0.5*(sigma + graph::sqrt(sigma*sigma + 4.0*(tau_sq + ustar*ustar))));
+        auto t = tau/gamma_next;
+        auto s = 1.0 + t->dot(t);
+        auto u_prime_dot_t = u_prime->dot(t);
+        auto u_next = (u_prime + u_prime_dot_t*t + u_prime->cross(t))/s;
+        auto pos_next = pos + larmor_radius*dt*u_next/gamma_next;
+
+        step.reset(new work_item<T> ({x, y, z, ux, uy, uz, gamma}, {},
+                                     {{pos_next->get_x(), x}, {pos_next->get_y(), y}, {pos_next->get_z(), z},
+                                      {u_next->get_x(), ux}, {u_next->get_y(), uy}, {u_next->get_z(), uz},
+                                      {gamma_next, gamma}}));
+    }
+
+    void print_info() const {
+        fprintf(stderr, "{\"axis_iterations\": %zu, \"axis_x\": %.17g, \"axis_z\": %.17g, \"b0\": %.17g, \"larmor_radius\": %.17g}\n",
+                axis_iterations, static_cast<double> (axis_x), static_cast<double> (axis_z),
+                static_cast<double> (b0_value), static_cast<double> (larmor_value));
+        fprintf(stderr, "step ");
+        step->code.print_counts(stderr);
+    }
+};
+
+//  korc <in: x y z ux uy uz gamma> <out> <num_steps> <save_every>
 //  Output: first record after initialize_gamma, then saved steps; b0 and larmor on stderr.
 template<typename T>
 static int cmd_korc(const raw_tables &raw, const char *in_path, const char *out_path,
                     const size_t num_steps, const size_t save_every) {
-    efit<T> eq(raw);
     size_t n;
     auto cols = convert<T> (read_columns(in_path, 7, n));
+    korc_graphs<T> g(raw);
+    g.print_info();
 
-//  get_characteristic_field
-    T b0_value;
-    {
-        auto x_axis = graph::variable<T> (1, "x");
-        auto y_axis = graph::variable<T> (1, "y");
-        auto z_axis = graph::variable<T> (1, "z");
-        auto b_vec = eq.get_magnetic_field(x_axis, y_axis, z_axis);
-        auto b_mod = b_vec->length();
-        auto func = (eq.psi_cache - eq.psimin)/eq.dpsi;
-        const T step = static_cast<T> (0.1);
-        work_item<T> newton({x_axis, y_axis, z_axis}, {func*func},
-                            {{x_axis - step*func/func->df(x_axis), x_axis},
-                             {z_axis - step*func/func->df(z_axis), z_axis}});
-        std::vector<std::vector<T>> axis = {{static_cast<T> (1.7)}, {static_cast<T> (0.0)}, {static_cast<T> (0.0)}};
-        T res, last;
-        const size_t it = converge(newton, 1, pointers(axis, 0, 3), &res, static_cast<T> (1.0E-30), 1000, &last);
-        work_item<T> bmod({x_axis, y_axis, z_axis}, {b_mod}, {});
-        bmod.run(1, pointers(axis, 0, 3), {&b0_value});
-        fprintf(stderr, "{\"axis_iterations\": %zu, \"axis_x\": %.17g, \"axis_z\": %.17g, \"b0\": %.17g",
-                it, static_cast<double> (axis[0][0]), static_cast<double> (axis[2][0]), static_cast<double> (b0_value));
-    }
-    auto b0 = graph::constant<T> (b0_value);
-    const T q = 1.602176634E-19;
-    const T me = 9.1093837139E-31;
-    const T c = 299792458.0;
-    auto gryo_period = me/(q*b0);
-    auto larmor_radius = c*gryo_period;
-    fprintf(stderr, ", \"larmor_radius\": %.17g}\n", static_cast<double> (larmor_radius->evaluate().at(0)));
-
-    auto ux = graph::variable<T> (1, "u_{x}");
-    auto uy = graph::variable<T> (1, "u_{y}");
-    auto uz = graph::variable<T> (1, "u_{z}");
-    auto x = graph::variable<T> (1, "x");
-    auto y = graph::variable<T> (1, "y");
-    auto z = graph::variable<T> (1, "z");
-    auto pos = graph::vector(x, y, z);
-    auto u_vec = graph::vector(ux, uy, uz);
-    auto gamma = graph::variable<T> (1, "\\gamma");
-    auto dt = graph::constant<T> (0.5);
-
-    auto gamma_init = 1.0/graph::sqrt(1.0 - u_vec->dot(u_vec));
-    auto u_init = gamma_init*u_vec;
-    auto b_vec = eq.get_magnetic_field(pos->get_x(), pos->get_y(), pos->get_z())/b0;
-
-    work_item<T> init({ux, uy, uz, gamma}, {},
-                      {{u_init->get_x(), ux}, {u_init->get_y(), uy}, {u_init->get_z(), uz}, {gamma_init, gamma}});
-
-    auto u_prime = u_vec - dt*u_vec->cross(b_vec)/(2.0*gamma);
-    auto tau = -0.5*dt*b_vec;
-    auto tau_sq = tau->dot(tau);
-    auto speed_sq = u_prime->dot(u_prime);
-    auto sigma = 1.0 + speed_sq - tau_sq;
-    auto ustar = u_prime->dot(tau);
-    auto gamma_next = graph::sqrt(0.5*(sigma + graph::sqrt(sigma*sigma + 4.0*(tau_sq + ustar*ustar))));
-    auto t = tau/gamma_next;
-    auto s = 1.0 + t->dot(t);
-    auto u_prime_dot_t = u_prime->dot(t);
-    auto u_next = (u_prime + u_prime_dot_t*t + u_prime->cross(t))/s;
-    auto pos_next = pos + larmor_radius*dt*u_next/gamma_next;
-
-    work_item<T> step({x, y, z, ux, uy, uz, gamma}, {},
-                      {{pos_next->get_x(), x}, {pos_next->get_y(), y}, {pos_next->get_z(), z},
-                       {u_next->get_x(), ux}, {u_next->get_y(), uy}, {u_next->get_z(), uz},
-                       {gamma_next, gamma}});
-    fprintf(stderr, "step ");
-    step.code.print_counts(stderr);
-
-    init.run(n, pointers(cols, 3, 4), {});
+    g.init->run(n, pointers(cols, 3, 4), {});
     std::vector<std::vector<double>> record;
     auto save = [&] () {
         for (size_t cidx = 0; cidx < 7; cidx++) record.emplace_back(cols[cidx].begin(), cols[cidx].end());
     };
     save();
     for (size_t k = 1; k <= num_steps; k++) {
-        step.run(n, pointers(cols, 0, 7), {});
+        g.step->run(n, pointers(cols, 0, 7), {});
         if (save_every && (k%save_every == 0 || k == num_steps)) save();
     }
     if (!save_every) save();
     write_columns(out_path, record);
+    return 0;
+}
+
+//  export_korc <dir> <suffix>: the four xkorc work items as GFIR.
+template<typename T>
+static int cmd_export_korc(const raw_tables &raw, const std::string dir, const std::string suffix) {
+    korc_graphs<T> g(raw);
+    g.print_info();
+    g.axis_newton->write_gfir("axis_newton", dir + "/korc_axis_newton_" + suffix + ".gfir");
+    g.bmod->write_gfir("bmod_at_axis", dir + "/korc_bmod_at_axis_" + suffix + ".gfir");
+    g.init->write_gfir("initialize_gamma", dir + "/korc_initialize_gamma_" + suffix + ".gfir");
+    g.step->write_gfir("step", dir + "/korc_step_" + suffix + ".gfir");
     return 0;
 }
 
@@ -1138,6 +1167,8 @@ static int dispatch(const raw_tables &raw, int argc, char **argv) {
     } else if (cmd == "trace" && argc == 10) {
         return cmd_trace<T> (raw, argv[4], argv[5], atof(argv[6]), strtoull(argv[7], nullptr, 10),
                              strtoull(argv[8], nullptr, 10), atoi(argv[9]));
+    } else if (cmd == "export_korc" && argc == 6) {
+        return cmd_export_korc<T> (raw, argv[4], argv[5]);
     } else if (cmd == "korc" && argc == 8) {
         return cmd_korc<T> (raw, argv[4], argv[5], strtoull(argv[6], nullptr, 10), strtoull(argv[7], nullptr, 10));
     }

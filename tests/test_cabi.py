@@ -1,0 +1,99 @@
+"""CPU tests of the drop-in boundary: libgf_hip.so loads, exports every symbol that
+include/gf_hip.h declares, and lowers work items without a device.  No compute calls."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, WORKLOADS
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from graph_framework_amd import build, _lib
+    build.build_library()
+    return _lib.load()
+
+
+def declared_symbols():
+    with open(os.path.join(ROOT, "include", "gf_hip.h")) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gfhip_[a-z_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from graph_framework_amd import _lib
+    names = declared_symbols()
+    assert len(names) >= 20
+    for name in names:
+        assert hasattr(lib, name), name
+    assert sorted(s[0] for s in _lib.SYMBOLS) == names
+
+
+def test_no_device_reports_cleanly(lib):
+    """In the CPU container there is no GPU: creation must fail with a message, never fall back."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from graph_framework_amd import Context, GfHipError
+    with pytest.raises(GfHipError):
+        Context(0)
+
+
+def test_lowering_without_a_device(lib):
+    from graph_framework_amd import generate_source
+    source, source_hash = generate_source(os.path.join(WORKLOADS, "solver_kernel_f64.gfir"))
+    assert "gfhip_solver_kernel" in source and source_hash != 0
+    # 8 gather index groups per RK4 step (4 stages x {(r,z) cell, psi bin}) instead of 360 index expressions
+    assert len(set(re.findall(r"const unsigned int (g\d+) =", source))) == 8
+    # tables that are exact multiples of another are not stored: 45 psi tables -> 20, 45 profile tables -> 12
+    assert len(set(re.findall(r"= pack0\[g\d+ \+ (\d+)u\]", source))) == 20
+    assert len(set(re.findall(r"= lds1\[g\d+ \+ (\d+)u\]", source))) == 12
+    # one reciprocal per distinct denominator (82), 680 divisions through it
+    assert len(re.findall(r"= gf_rcp\(", source)) == 82
+    assert len(re.findall(r"= gf_div\(r", source)) == 680
+    again, again_hash = generate_source(os.path.join(WORKLOADS, "solver_kernel_f64.gfir"))
+    assert again == source and again_hash == source_hash
+
+
+def test_malformed_items_are_rejected(lib):
+    from graph_framework_amd import generate_source, GfHipError
+    with open(os.path.join(WORKLOADS, "korc_initialize_gamma_f64.gfir"), "rb") as f:
+        good = f.read()
+    generate_source(good)
+    huge_counts = b"GFIR0001" + bytes([1, 0, 0, 0]) + bytes([255]*20) + bytes(100)
+    for bad in (b"", b"not a work item", good[:40], good[:-3], huge_counts):
+        with pytest.raises(GfHipError):
+            generate_source(bad)
+    corrupt = bytearray(good)
+    corrupt[8] = 7                       # dtype
+    with pytest.raises(GfHipError):
+        generate_source(bytes(corrupt))
+
+
+def test_table_compaction_is_exact():
+    """Every table the lowering derives as k*parent must equal the exported table bit for bit."""
+    import struct
+    from graph_framework_amd import generate_source
+    path = os.path.join(WORKLOADS, "solver_kernel_f64.gfir")
+    source, _ = generate_source(path)
+    data = open(path, "rb").read()
+    magic, dtype, ni, no, ns, nt, nins, nb, _r = struct.unpack_from("<8s8I", data, 0)
+    pos = 40 + nb
+    for _ in range(ni):
+        (n,) = struct.unpack_from("<I", data, pos)
+        pos += 4 + n
+    tables = []
+    for _ in range(nt):
+        r, c = struct.unpack_from("<II", data, pos)
+        pos += 8
+        tables.append(np.frombuffer(data, dtype="<f8", count=r*c, offset=pos))
+        pos += 8*r*c
+    derived = re.findall(r"const real c(\d+)_(\d+) = (\S+)\*c\d+_(\d+);", source)
+    assert len(derived) > 100
+    for _group, child, factor, parent in derived:
+        k = float.fromhex(factor)
+        np.testing.assert_array_equal(k*tables[int(parent)], tables[int(child)])
