@@ -66,6 +66,12 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise ImportError("graph_framework_amd: %s is missing — run __graft_entry__.build() "
                               "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+#  torch bundles its own HIP runtime; load it first so that the process has ONE libamdhip64
+#  (two runtimes in one process cannot both open the device).  torch is only plumbing here.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = ctypes.CDLL(LIB_PATH)
         for name, restype, argtypes in SYMBOLS:
             fn = getattr(lib, name)

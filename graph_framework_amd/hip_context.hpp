@@ -1,0 +1,333 @@
+//------------------------------------------------------------------------------
+///  @file hip_context.hpp
+///  @brief gpu::hip_context — the MI355X backend context for graph_framework.
+///
+///  Drop this header next to graph_framework/cuda_context.hpp and select it in
+///  jit.hpp with -DUSE_HIP (INTEGRATION.md shows the three-line patch).  It has
+///  the duck-typed interface jit::context<T, SAFE_MATH> forwards to
+///  (graph_framework/jit.hpp:63-74, :87-338; same members as gpu::cpu_context,
+///  cpu_context.hpp:82-611, and gpu::cuda_context, cuda_context.hpp:73-1005).
+///
+///  Unlike the CPU/CUDA/Metal contexts it does not compile the C++ text the
+///  nodes write: create_kernel_prefix/create_kernel_postfix receive the work
+///  item's node lists, the DAG is serialized to GFIR (gfir_serialize.hpp) and
+///  handed to libgf_hip.so (include/gf_hip.h), which lowers it to a gfx950
+///  kernel.  The text stream is still fed (registers must exist for the nodes'
+///  compile() methods to run) but is otherwise ignored.
+///
+///  Real base types only: complex types and SAFE_MATH guards
+///  (cpu_context.hpp:530-547) and random state kernels are not on this path
+///  and abort with a message, like the reference's own unsupported cases.
+//------------------------------------------------------------------------------
+#ifndef hip_context_h
+#define hip_context_h
+
+#include <cstdlib>
+#include <functional>
+#include <iostream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "random.hpp"
+
+#include "../include/gf_hip.h"
+#include "gfir_serialize.hpp"
+
+namespace gpu {
+//------------------------------------------------------------------------------
+///  @brief Class representing a HIP gpu context.
+///
+///  @tparam T         Base type of the calculation.
+///  @tparam SAFE_MATH Use @ref general_concepts_safe_math operations.
+//------------------------------------------------------------------------------
+    template<jit::float_scalar T, bool SAFE_MATH=false>
+    class hip_context {
+    private:
+///  Handle of the C ABI context (one device, one stream).
+        gfhip_context *context;
+
+///  A work item between create_kernel_prefix and compile.
+        struct pending_item {
+            std::string name;
+            graph::input_nodes<T, SAFE_MATH> inputs;
+            graph::output_nodes<T, SAFE_MATH> outputs;
+            size_t size;
+            std::vector<uint8_t> gfir;
+        };
+        std::vector<pending_item> pending;
+        std::map<std::string, gfhip_kernel *> kernels;
+///  Kernel whose last output is a node (for create_max_call).
+        std::map<graph::leaf_node<T, SAFE_MATH> *, gfhip_kernel *> reductions;
+///  Host mirrors handed out by get_buffer, refreshed in wait().
+        std::map<graph::leaf_node<T, SAFE_MATH> *, std::vector<T>> host_buffers;
+
+        static uint64_t key(graph::leaf_node<T, SAFE_MATH> *node) {
+            return static_cast<uint64_t> (reinterpret_cast<uintptr_t> (node));
+        }
+
+        void check(const int status, const char *what) const {
+            if (status) {
+                std::cerr << "hip_context: " << what << ": " << gfhip_last_error(context) << std::endl;
+                exit(-1);
+            }
+        }
+
+    public:
+///  Size of random state needed.
+        constexpr static size_t random_state_size = 1024;
+
+///  Remaining constant memory in bytes (tables live in packed global/LDS arrays).
+        int remaining_const_memory;
+
+//------------------------------------------------------------------------------
+///  @brief Get the maximum number of concurrent instances.
+//------------------------------------------------------------------------------
+        static size_t max_concurrency() {
+            return static_cast<size_t> (gfhip_max_concurrency());
+        }
+
+//------------------------------------------------------------------------------
+///  @brief Device discription.
+//------------------------------------------------------------------------------
+        static std::string device_type() {
+            return gfhip_device_type();
+        }
+
+//------------------------------------------------------------------------------
+///  @brief Construct a HIP context.
+///
+///  @param[in] index Concurrent index.
+//------------------------------------------------------------------------------
+        hip_context(const size_t index) : remaining_const_memory(0) {
+            if constexpr (jit::complex_scalar<T> || SAFE_MATH) {
+                std::cerr << "hip_context: complex base types and SAFE_MATH are not served by the HIP backend."
+                          << std::endl;
+                exit(-1);
+            }
+            context = gfhip_create_context(static_cast<int> (index), nullptr);
+            if (!context) {
+                std::cerr << "hip_context: " << gfhip_last_error(nullptr) << std::endl;
+                exit(-1);
+            }
+        }
+
+        ~hip_context() {
+            gfhip_destroy_context(context);
+        }
+
+//------------------------------------------------------------------------------
+///  @brief Create the source header (nothing to declare: the text is not compiled).
+//------------------------------------------------------------------------------
+        void create_header(std::ostringstream &source_buffer) {
+            source_buffer << "// hip_context lowers the node graph directly; this text is informational."
+                          << std::endl;
+        }
+
+//------------------------------------------------------------------------------
+///  @brief Begin a kernel: record its name, inputs, outputs and size.
+///
+///  Every input needs a register name because the nodes' compile() methods look
+///  it up (cpu_context.hpp:489-500 does the same).
+//------------------------------------------------------------------------------
+        void create_kernel_prefix(std::ostringstream &source_buffer,
+                                  const std::string name,
+                                  graph::input_nodes<T, SAFE_MATH> &inputs,
+                                  graph::output_nodes<T, SAFE_MATH> &outputs,
+                                  graph::shared_random_state<T, SAFE_MATH> state,
+                                  const size_t size,
+                                  const std::vector<bool> &is_constant,
+                                  jit::register_map &registers,
+                                  const jit::register_usage &usage,
+                                  jit::texture1d_list &textures1d,
+                                  jit::texture2d_list &textures2d) {
+            (void)is_constant; (void)usage; (void)textures1d; (void)textures2d;
+            if (state.get()) {
+                std::cerr << "hip_context: kernels with a random state are not served by the HIP backend."
+                          << std::endl;
+                exit(-1);
+            }
+            source_buffer << "// kernel " << name << std::endl;
+            for (auto &input : inputs) {
+                registers[input.get()] = jit::to_string('v', input.get());
+            }
+            pending_item item;
+            item.name = name;
+            item.inputs = inputs;
+            item.outputs = outputs;
+            item.size = size;
+            pending.push_back(item);
+        }
+
+//------------------------------------------------------------------------------
+///  @brief End a kernel: the setters complete the work item; serialize it.
+//------------------------------------------------------------------------------
+        void create_kernel_postfix(std::ostringstream &source_buffer,
+                                   graph::output_nodes<T, SAFE_MATH> &outputs,
+                                   graph::map_nodes<T, SAFE_MATH> &setters,
+                                   graph::shared_random_state<T, SAFE_MATH> state,
+                                   jit::register_map &registers,
+                                   jit::register_map &indices,
+                                   const jit::register_usage &usage) {
+            (void)outputs; (void)state; (void)registers; (void)indices; (void)usage;
+            source_buffer << "// end kernel" << std::endl;
+            if constexpr (!jit::complex_scalar<T>) {
+                pending_item &item = pending.back();
+                gfir::serializer<T, SAFE_MATH> serialize;
+                item.gfir = serialize(item.name, item.inputs, item.outputs, setters);
+            }
+        }
+
+//------------------------------------------------------------------------------
+///  @brief Create a reduction (the device max reduction is part of libgf_hip).
+//------------------------------------------------------------------------------
+        void create_reduction(std::ostringstream &source_buffer, const size_t size) {
+            (void)source_buffer; (void)size;
+        }
+
+//------------------------------------------------------------------------------
+///  @brief Compile the kernels.
+///
+///  @param[in] kernel_source Source text (ignored).
+///  @param[in] names         Names of the kernel functions.
+///  @param[in] add_reduction Include the reduction kernel (always available).
+//------------------------------------------------------------------------------
+        void compile(const std::string kernel_source,
+                     std::vector<std::string> names,
+                     const bool add_reduction=false) {
+            (void)kernel_source; (void)names; (void)add_reduction;
+            for (auto &item : pending) {
+                gfhip_kernel *kernel = gfhip_add_kernel(context, item.gfir.data(), item.gfir.size(), item.size);
+                if (!kernel) {
+                    check(1, "gfhip_add_kernel");
+                }
+                kernels[item.name] = kernel;
+            }
+            pending.clear();
+            check(gfhip_compile(context), "gfhip_compile");
+        }
+
+//------------------------------------------------------------------------------
+///  @brief Create a kernel calling function.
+///
+///  Buffers are keyed by node; a node seen for the first time is allocated and,
+///  for inputs, filled with node->evaluate() (cuda_context.hpp:316-383).
+//------------------------------------------------------------------------------
+        std::function<void(void)> create_kernel_call(const std::string kernel_name,
+                                                     graph::input_nodes<T, SAFE_MATH> inputs,
+                                                     graph::output_nodes<T, SAFE_MATH> outputs,
+                                                     graph::shared_random_state<T, SAFE_MATH> state,
+                                                     const size_t num_rays,
+                                                     const jit::texture1d_list &tex1d_list,
+                                                     const jit::texture2d_list &tex2d_list) {
+            (void)state; (void)num_rays; (void)tex1d_list; (void)tex2d_list;
+            gfhip_kernel *kernel = kernels.at(kernel_name);
+
+            std::vector<uint64_t> input_keys, output_keys;
+            std::vector<backend::buffer<T>> initial;
+            std::vector<const void *> initial_pointers;
+            for (auto &input : inputs) {
+                input_keys.push_back(key(input.get()));
+                initial.push_back(input->evaluate());
+            }
+            for (auto &buffer : initial) {
+                initial_pointers.push_back(buffer.data());
+            }
+            for (auto &output : outputs) {
+                output_keys.push_back(key(output.get()));
+            }
+            check(gfhip_create_kernel_call(kernel, input_keys.data(), initial_pointers.data(),
+                                           output_keys.data()), "gfhip_create_kernel_call");
+            if (!outputs.empty()) {
+                reductions[outputs.back().get()] = kernel;
+            }
+
+            return [this, kernel] () mutable {
+                check(gfhip_run(kernel, 1), "gfhip_run");
+            };
+        }
+
+//------------------------------------------------------------------------------
+///  @brief Create a max compute kernel calling function.
+//------------------------------------------------------------------------------
+        std::function<T(void)> create_max_call(graph::shared_leaf<T, SAFE_MATH> &argument,
+                                               std::function<void(void)> run) {
+            (void)run;
+            gfhip_kernel *kernel = reductions.at(argument.get());
+            return [this, kernel] () mutable {
+                double value;
+                check(gfhip_run_max(kernel, &value), "gfhip_run_max");
+                return static_cast<T> (value);
+            };
+        }
+
+//------------------------------------------------------------------------------
+///  @brief Hold the current thread until the stream has completed; refresh host mirrors.
+//------------------------------------------------------------------------------
+        void wait() {
+            check(gfhip_wait(context), "gfhip_wait");
+            for (auto &[node, buffer] : host_buffers) {
+                check(gfhip_copy_to_host(context, key(node), buffer.data()), "gfhip_copy_to_host");
+            }
+        }
+
+//------------------------------------------------------------------------------
+///  @brief Print out the results.
+//------------------------------------------------------------------------------
+        void print_results(const size_t index,
+                           const graph::output_nodes<T, SAFE_MATH> &nodes) {
+            for (auto &out : nodes) {
+                std::cout << check_value(index, out) << " ";
+            }
+            std::cout << std::endl;
+        }
+
+//------------------------------------------------------------------------------
+///  @brief Check the value.
+//------------------------------------------------------------------------------
+        T check_value(const size_t index,
+                      const graph::shared_leaf<T, SAFE_MATH> &node) {
+            double value;
+            check(gfhip_check_value(context, key(node.get()), index, &value), "gfhip_check_value");
+            return static_cast<T> (value);
+        }
+
+//------------------------------------------------------------------------------
+///  @brief Copy buffer contents to the device.
+//------------------------------------------------------------------------------
+        void copy_to_device(graph::shared_leaf<T, SAFE_MATH> node,
+                            T *source) {
+            check(gfhip_copy_to_device(context, key(node.get()), source), "gfhip_copy_to_device");
+        }
+
+//------------------------------------------------------------------------------
+///  @brief Copy buffer contents to host (complete on return).
+//------------------------------------------------------------------------------
+        void copy_to_host(graph::shared_leaf<T, SAFE_MATH> node,
+                          T *destination) {
+            check(gfhip_copy_to_host(context, key(node.get()), destination), "gfhip_copy_to_host");
+        }
+
+//------------------------------------------------------------------------------
+///  @brief Get a stable host-readable buffer for a node (output.hpp:271).
+///
+///  The pointer stays valid for the life of the context and holds the device
+///  contents as of the last wait().
+//------------------------------------------------------------------------------
+        T *get_buffer(graph::shared_leaf<T, SAFE_MATH> &node) {
+            auto found = host_buffers.find(node.get());
+            if (found == host_buffers.end()) {
+                size_t count = 0;
+                if (!gfhip_get_buffer(context, key(node.get()), &count)) {
+                    check(1, "gfhip_get_buffer");
+                }
+                found = host_buffers.insert({node.get(), std::vector<T> (count)}).first;
+                check(gfhip_copy_to_host(context, key(node.get()), found->second.data()), "gfhip_copy_to_host");
+            }
+            return found->second.data();
+        }
+    };
+}
+
+#endif /* hip_context_h */

@@ -94,7 +94,12 @@ class Item:
         max of its last output stalls.  Returns (iterations, last max, outputs)."""
         def max_kernel():
             outs, _ = self.run(columns)
-            return float(outs[-1].max()), outs
+            values = outs[-1]
+#  std::max_element (cpu_context.hpp:306-322): `m < x` is false for NaN, so a NaN is never
+#  selected unless it is the first element.
+            if np.isnan(values[0]):
+                return float("nan"), outs
+            return float(np.fmax.reduce(values)), outs
 
         big = float(np.finfo(self.np_dtype).max)
         iterations = 0
