@@ -29,6 +29,7 @@
 #ifndef gfhip_codegen_hpp
 #define gfhip_codegen_hpp
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -65,6 +66,7 @@ struct lowered {
     std::vector<double> table_factor;
     uint32_t block_size = 256;
     size_t lds_bytes = 0;
+    uint32_t park_slots = 0;            ///< LDS slots used for parked values
     uint64_t hash = 0;
 };
 
@@ -75,11 +77,21 @@ struct codegen_options {
     bool shared_reciprocal = true;      ///< fp64 divisions by one denominator share its refined reciprocal
     bool pow_three_halves = true;       ///< fp64 pow(x, 1.5) as a compensated x*sqrt(x)
     bool compact_tables = true;         ///< store only tables that are not an exact multiple of another
+    bool park_in_lds = false;           ///< EXPERIMENT (GFHIP_PARK=1): long-lived values wait in LDS; measured slower, see DESIGN.md
+    uint32_t park_min_range = 300;      ///< park values whose live range exceeds this many nodes ...
+    uint32_t park_window = 48;          ///< ... uses closer than this share one reload
+    uint32_t park_max_slots = 64;       ///< LDS slots of block_size elements each
+    uint32_t park_prefetch = 32;        ///< issue a reload this many nodes before its first use (< window)
 
 //  Environment overrides (they change the generated text, hence the cache key).
     static codegen_options from_environment() {
         codegen_options o;
         if (const char *e = std::getenv("GFHIP_DIVISION")) o.shared_reciprocal = std::string(e) != "ieee";
+        if (const char *e = std::getenv("GFHIP_PARK")) o.park_in_lds = std::string(e) == "1";
+        if (const char *e = std::getenv("GFHIP_PARK_MIN_RANGE")) o.park_min_range = static_cast<uint32_t> (std::atoi(e));
+        if (const char *e = std::getenv("GFHIP_PARK_WINDOW")) o.park_window = static_cast<uint32_t> (std::atoi(e));
+        if (const char *e = std::getenv("GFHIP_PARK_PREFETCH")) o.park_prefetch = static_cast<uint32_t> (std::atoi(e));
+        if (const char *e = std::getenv("GFHIP_PARK_MAX_SLOTS")) o.park_max_slots = static_cast<uint32_t> (std::atoi(e));
         if (const char *e = std::getenv("GFHIP_COMPACT_TABLES")) o.compact_tables = std::string(e) != "0";
         if (const char *e = std::getenv("GFHIP_POW")) o.pow_three_halves = std::string(e) != "libm";
         if (const char *e = std::getenv("GFHIP_WAVES_PER_SIMD")) o.waves_per_simd = static_cast<uint32_t> (std::atoi(e));
@@ -246,8 +258,98 @@ inline lowered lower(const item &it, const codegen_options &opt = codegen_option
             }
         }
     }
-    out.lds_bytes = lds_used;
     out.block_size = opt.block_size;
+
+//  LDS parking (off by default: on MI355X it removes the scratch spills and 20 % of the AGPR
+//  moves but the ordered LDS reads cost more than they save — 0.46 ms vs 0.36 ms per step).
+//  The RK4 item keeps ~150 fp64 values alive (stage results, the state, shared
+//  sub-expressions of the seven partials); at 512 registers per lane the compiler shuttles
+//  them through AGPRs (two VALU moves each way) and scratch (HBM write traffic).  Values
+//  whose live range is long and whose uses cluster are instead written once to a per-lane
+//  LDS slot (`park[slot*block + lane]`, conflict free, LDS pipe instead of VALU) and read
+//  back at the first use of every later cluster.  Pure data movement: bits unchanged.
+    const size_t node_count = it.code.size();
+    struct park_plan {
+        bool parked = false;
+        uint32_t slot = 0;
+        std::map<size_t, uint32_t> reload_at;       ///< position -> cluster number
+    };
+    std::vector<park_plan> plan(node_count);
+    uint32_t park_slots = 0;
+//  A workgroup may declare all 160 KiB of a CU's LDS; stay inside it.
+    const size_t lds_capacity = 160*1024;
+    const size_t slot_bytes = static_cast<size_t> (opt.block_size)*esize;
+    const uint32_t slot_limit = lds_used < lds_capacity
+                              ? static_cast<uint32_t> (std::min<size_t> (opt.park_max_slots, (lds_capacity - lds_used)/slot_bytes))
+                              : 0;
+    if (opt.park_in_lds && slot_limit > 0) {
+        std::vector<std::vector<size_t>> uses(node_count);
+        auto arity = [] (const uint32_t op) -> int {
+            switch (op) {
+                case GFIR_CONST: case GFIR_INPUT: return 0;
+                case GFIR_FMA: return 3;
+                case GFIR_SQRT: case GFIR_POWI: case GFIR_SIN: case GFIR_COS: case GFIR_EXP: case GFIR_LOG:
+                case GFIR_GATHER1: return 1;
+                default: return 2;
+            }
+        };
+        for (size_t i = 0; i < node_count; i++) {
+            const gfir_instruction &c = it.code[i];
+            const uint32_t operands[3] = {c.a, c.b, c.c};
+            for (int k = 0; k < arity(c.op); k++) {
+                if (uses[operands[k]].empty() || uses[operands[k]].back() != i) uses[operands[k]].push_back(i);
+            }
+        }
+        for (auto &st : it.setters) uses[st.value].push_back(node_count);
+        for (auto o : it.outputs) uses[o].push_back(node_count);
+
+        struct candidate { size_t def, last; uint32_t value; };
+        std::vector<candidate> candidates;
+        for (size_t v = 0; v < node_count; v++) {
+            const uint32_t op = it.code[v].op;
+            if (op == GFIR_CONST || op == GFIR_INPUT || uses[v].empty()) continue;
+            if (uses[v].back() - v < opt.park_min_range) continue;
+            size_t previous = v;
+            uint32_t cluster = 0;
+            std::map<size_t, uint32_t> reloads;
+            const size_t prefetch = opt.park_prefetch < opt.park_window ? opt.park_prefetch : opt.park_window - 1;
+            for (const size_t u : uses[v]) {
+                if (u - previous > opt.park_window) {
+//  Issue the LDS read `prefetch` nodes ahead of the first use of the cluster (there is no
+//  other use of the value in that gap: clusters are further apart than the window).
+                    reloads[u - prefetch] = ++cluster;
+                }
+                previous = u;
+            }
+            if (reloads.empty()) continue;
+            plan[v].reload_at = reloads;
+            candidates.push_back({v, uses[v].back(), static_cast<uint32_t> (v)});
+        }
+//  Linear-scan slot allocation in definition order; a slot is free after the last reload.
+        std::vector<size_t> slot_free_at;
+        for (auto &c : candidates) {
+            const size_t last_reload = plan[c.value].reload_at.rbegin()->first;
+            uint32_t slot = static_cast<uint32_t> (slot_free_at.size());
+            for (uint32_t k = 0; k < slot_free_at.size(); k++) {
+                if (slot_free_at[k] < c.def) { slot = k; break; }
+            }
+            if (slot == slot_free_at.size()) {
+                if (slot_free_at.size() >= slot_limit) {
+                    plan[c.value].reload_at.clear();
+                    continue;
+                }
+                slot_free_at.push_back(0);
+            }
+            slot_free_at[slot] = last_reload;
+            plan[c.value].parked = true;
+            plan[c.value].slot = slot;
+        }
+        park_slots = static_cast<uint32_t> (slot_free_at.size());
+    }
+    const size_t park_offset = lds_used;
+    lds_used += static_cast<size_t> (park_slots)*opt.block_size*esize;
+    out.lds_bytes = lds_used;
+    out.park_slots = park_slots;
 
     std::ostringstream s;
     out.kernel_name = "gfhip_" + it.name;
@@ -315,6 +417,12 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
             offset += (count*esize + 15)/16*16;
         }
         s << "    __syncthreads();\n";
+        if (park_slots) {
+            //  volatile: no store-to-load forwarding (that would put the value back in a register);
+//  explicit LDS address space so the accesses stay ds_write_b64/ds_read_b64.
+            s << "    typedef volatile __attribute__((address_space(3))) real park_t;\n";
+            s << "    park_t *park = (park_t *)(lds_raw + " << park_offset << ") + threadIdx.x;\n";
+        }
     }
 
     s << "    for (unsigned long long i = blockIdx.x*static_cast<unsigned long long> (blockDim.x) + threadIdx.x; i < n;\n"
@@ -346,6 +454,10 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
         std::map<uint32_t, bool> reciprocal_done;
         std::set<std::string> coefficients;
         size_t group_count = 0;
+//  Current name of every value (changes when a parked value is reloaded).
+        std::vector<std::string> name(node_count);
+        for (size_t v = 0; v < node_count; v++) name[v] = "r" + std::to_string(v);
+        auto name_of = [&] (const uint32_t v) -> std::string { return name[v]; };
         auto index_expression = [&] (const uint32_t arg, const double scale, const double offset,
                                      const uint32_t length) -> std::string {
             std::ostringstream e;
@@ -353,18 +465,33 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
             if (shared) {
 //  The reciprocal literal is the correctly rounded 1/scale; gf_div's residual step makes
 //  the quotient the correctly rounded (r - offset)/scale.
-                e << "gf_div(r" << arg << " - " << literal(offset) << ", " << literal(scale) << ", "
+                e << "gf_div(" << name_of(arg) << " - " << literal(offset) << ", " << literal(scale) << ", "
                   << literal(f64 ? 1.0/scale : static_cast<double> (1.0f/static_cast<float> (scale))) << ")";
             } else {
-                e << "(r" << arg << " - " << literal(offset) << ")/" << literal(scale);
+                e << "(" << name_of(arg) << " - " << literal(offset) << ")/" << literal(scale);
             }
             e << ", " << literal(0.0) << "), " << literal(static_cast<double> (length - 1)) << "))";
             return e.str();
         };
 
         const char *ind = "                ";
+        std::map<size_t, std::vector<uint32_t>> reloads_at_position;
+        for (size_t v = 0; v < node_count; v++) {
+            if (!plan[v].parked) continue;
+            for (auto &kv : plan[v].reload_at) reloads_at_position[kv.first].push_back(static_cast<uint32_t> (v));
+        }
+        auto reload = [&] (const size_t position) {
+            auto found = reloads_at_position.find(position);
+            if (found == reloads_at_position.end()) return;
+            for (const uint32_t v : found->second) {
+                name[v] = "r" + std::to_string(v) + "p" + std::to_string(plan[v].reload_at[position]);
+                s << ind << "const real " << name[v] << " = park[" << plan[v].slot*out.block_size << "u];\n";
+            }
+        };
+        auto N = [&] (const uint32_t v) -> const std::string & { return name[v]; };
         for (size_t i = 0; i < it.code.size(); i++) {
             const gfir_instruction &c = it.code[i];
+            reload(i);
             switch (c.op) {
                 case GFIR_CONST:
                     s << ind << "const real r" << i << " = " << literal(c.imm[0]) << ";\n";
@@ -373,37 +500,37 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
                     s << ind << "const real r" << i << " = v" << c.a << ";\n";
                     break;
                 case GFIR_ADD:
-                    s << ind << "const real r" << i << " = r" << c.a << " + r" << c.b << ";\n";
+                    s << ind << "const real r" << i << " = " << N(c.a) << " + " << N(c.b) << ";\n";
                     break;
                 case GFIR_SUB:
-                    s << ind << "const real r" << i << " = r" << c.a << " - r" << c.b << ";\n";
+                    s << ind << "const real r" << i << " = " << N(c.a) << " - " << N(c.b) << ";\n";
                     break;
                 case GFIR_MUL:
-                    s << ind << "const real r" << i << " = r" << c.a << "*r" << c.b << ";\n";
+                    s << ind << "const real r" << i << " = " << N(c.a) << "*" << N(c.b) << ";\n";
                     break;
                 case GFIR_DIV:
                     if (shared) {
                         if (!reciprocal_done[c.b]) {
                             reciprocal_done[c.b] = true;
-                            s << ind << "const real q" << c.b << " = gf_rcp(r" << c.b << ");\n";
-                            s << ind << "dmax = __builtin_fmax(dmax, __builtin_fabs(r" << c.b << "));\n";
-                            s << ind << "dmin = __builtin_fmin(dmin, __builtin_fabs(r" << c.b << "));\n";
+                            s << ind << "const real q" << c.b << " = gf_rcp(" << N(c.b) << ");\n";
+                            s << ind << "dmax = __builtin_fmax(dmax, __builtin_fabs(" << N(c.b) << "));\n";
+                            s << ind << "dmin = __builtin_fmin(dmin, __builtin_fabs(" << N(c.b) << "));\n";
                         }
-                        s << ind << "const real r" << i << " = gf_div(r" << c.a << ", r" << c.b << ", q" << c.b << ");\n";
+                        s << ind << "const real r" << i << " = gf_div(" << N(c.a) << ", " << N(c.b) << ", q" << c.b << ");\n";
                     } else {
-                        s << ind << "const real r" << i << " = r" << c.a << "/r" << c.b << ";\n";
+                        s << ind << "const real r" << i << " = " << N(c.a) << "/" << N(c.b) << ";\n";
                     }
                     break;
                 case GFIR_FMA:
-                    s << ind << "const real r" << i << " = __builtin_fma" << sfx << "(r" << c.a << ", r" << c.b
-                      << ", r" << c.c << ");\n";
+                    s << ind << "const real r" << i << " = __builtin_fma" << sfx << "(" << N(c.a) << ", " << N(c.b)
+                      << ", " << N(c.c) << ");\n";
                     break;
                 case GFIR_SQRT:
-                    s << ind << "const real r" << i << " = __builtin_sqrt" << sfx << "(r" << c.a << ");\n";
+                    s << ind << "const real r" << i << " = __builtin_sqrt" << sfx << "(" << N(c.a) << ");\n";
                     break;
                 case GFIR_POWI: {
-                    s << ind << "const real r" << i << " = r" << c.a;
-                    for (uint32_t k = 1; k < c.aux; k++) s << "*r" << c.a;
+                    s << ind << "const real r" << i << " = " << N(c.a);
+                    for (uint32_t k = 1; k < c.aux; k++) s << "*" << N(c.a);
                     s << ";\n";
                     break;
                 }
@@ -411,23 +538,23 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
                     if (f64 && opt.pow_three_halves && it.code[c.b].op == GFIR_CONST && it.code[c.b].imm[0] == 1.5) {
                         s << ind << "const real r" << i << " = gf_pow_three_halves(r" << c.a << ");\n";
                     } else {
-                        s << ind << "const real r" << i << " = pow" << sfx << "(r" << c.a << ", r" << c.b << ");\n";
+                        s << ind << "const real r" << i << " = pow" << sfx << "(" << N(c.a) << ", " << N(c.b) << ");\n";
                     }
                     break;
                 case GFIR_SIN:
-                    s << ind << "const real r" << i << " = sin" << sfx << "(r" << c.a << ");\n";
+                    s << ind << "const real r" << i << " = sin" << sfx << "(" << N(c.a) << ");\n";
                     break;
                 case GFIR_COS:
-                    s << ind << "const real r" << i << " = cos" << sfx << "(r" << c.a << ");\n";
+                    s << ind << "const real r" << i << " = cos" << sfx << "(" << N(c.a) << ");\n";
                     break;
                 case GFIR_ATAN2:
-                    s << ind << "const real r" << i << " = atan2" << sfx << "(r" << c.b << ", r" << c.a << ");\n";
+                    s << ind << "const real r" << i << " = atan2" << sfx << "(" << N(c.b) << ", " << N(c.a) << ");\n";
                     break;
                 case GFIR_EXP:
-                    s << ind << "const real r" << i << " = exp" << sfx << "(r" << c.a << ");\n";
+                    s << ind << "const real r" << i << " = exp" << sfx << "(" << N(c.a) << ");\n";
                     break;
                 case GFIR_LOG:
-                    s << ind << "const real r" << i << " = log" << sfx << "(r" << c.a << ");\n";
+                    s << ind << "const real r" << i << " = log" << sfx << "(" << N(c.a) << ");\n";
                     break;
                 case GFIR_GATHER1:
                 case GFIR_GATHER2: {
@@ -472,12 +599,16 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
                 default:
                     s << ind << "#error unsupported GFIR op\n";
             }
+            if (plan[i].parked) {
+                s << ind << "park[" << plan[i].slot*out.block_size << "u] = r" << i << ";\n";
+            }
         }
+        reload(node_count);
         for (size_t k = 0; k < it.setters.size(); k++) {
-            s << ind << "sv" << k << " = r" << it.setters[k].value << ";\n";
+            s << ind << "sv" << k << " = " << N(it.setters[k].value) << ";\n";
         }
         for (size_t o = 0; o < it.outputs.size(); o++) {
-            s << ind << "so" << o << " = r" << it.outputs[o] << ";\n";
+            s << ind << "so" << o << " = " << N(it.outputs[o]) << ";\n";
         }
     };
 
