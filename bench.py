@@ -29,17 +29,34 @@ BYTES_PER_RAY_STEP_F64 = 128      # read 8 + write 8 (7 setters + residual) x 8 
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def cpu_baseline(num_rays, steps, threads):
-    """The CPU oracle (oracle/gfir_interp.c: the reference DAG, strict IEEE, one thread per
-    core, contiguous shards) timed on a bounded sample of the same workload."""
+def cpu_baseline(target_seconds=15.0):
+    """The CPU oracle timed on a bounded sample of the same workload: the solver_kernel DAG as
+    the reference's cpu_context runs it (one compiled statement per node, serial loop per
+    thread, contiguous shards; oracle/gfir_to_c.py, gcc -O2, strict IEEE), one thread per
+    available core.  Falls back to the interpreter (oracle/gfir_interp.c) without gcc."""
     from oracle import gfir
     from graph_framework_amd.xrays import STATE, workload
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
     state = dict(t=0.0, w=500.0, x=2.5, y=0.0, z=0.0, kx=-600.0, ky=0.0, kz=0.0)
-    columns = [np.full(num_rays, state[k]) for k in STATE]
+    rays = 256*cores
+    columns = [np.full(rays, state[k]) for k in STATE]
     gfir.Item(workload("loss_kernel_kx")).converge(columns)
-    item = gfir.Item(workload("solver_kernel"))
-    _, seconds = item.run(columns, steps=steps, threads=threads)
-    return num_rays*steps/seconds, seconds
+    how = "compiled by gcc from the DAG (oracle/gfir_to_c.py)"
+    try:
+        from oracle import gfir_to_c
+        item = gfir_to_c.CompiledItem(workload("solver_kernel"))
+    except Exception:
+        item = gfir.Item(workload("solver_kernel"))
+        how = "interpreted by oracle/gfir_interp.c"
+    _, probe = item.run(columns, steps=2, threads=cores)
+    steps = int(max(2, min(2000, target_seconds/(probe/2.0))))
+    _, seconds = item.run(columns, steps=steps, threads=cores)
+    sample = ("%d rays x %d RK4 steps of the same solver_kernel DAG, strict IEEE, %s, %d threads (%.1f s)"
+              % (rays, steps, how, cores, seconds))
+    return rays*steps/seconds, cores, sample
 
 
 def main():
@@ -146,13 +163,9 @@ def main():
         if gather_seconds is not None:
             line["all_gather_seconds"] = gather_seconds
         if world == 1 and not args.no_cpu_baseline:
-            cores = os.cpu_count() or 1
-            sample_rays, sample_steps = 64*cores, 40
-            rate, seconds = cpu_baseline(sample_rays, sample_steps, cores)
+            rate, cores, sample = cpu_baseline()
             line["cpu_baseline"] = {"value": rate, "unit": "ray-steps/s", "cores": cores, "kind": "port",
-                                    "sample": "%d rays x %d RK4 steps of the same solver_kernel DAG, interpreted "
-                                              "in strict IEEE by oracle/gfir_interp.c on %d threads (%.1f s)"
-                                              % (sample_rays, sample_steps, cores, seconds)}
+                                    "sample": sample}
         print(json.dumps(line))
 
 

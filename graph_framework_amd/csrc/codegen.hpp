@@ -77,19 +77,21 @@ struct codegen_options {
     bool shared_reciprocal = true;      ///< fp64 divisions by one denominator share its refined reciprocal
     bool pow_three_halves = true;       ///< fp64 pow(x, 1.5) as a compensated x*sqrt(x)
     bool compact_tables = true;         ///< store only tables that are not an exact multiple of another
-    bool park_in_lds = false;           ///< EXPERIMENT (GFHIP_PARK=1): long-lived values wait in LDS; measured slower, see DESIGN.md
-    uint32_t park_min_range = 300;      ///< park values whose live range exceeds this many nodes ...
-    uint32_t park_window = 48;          ///< ... uses closer than this share one reload
-    uint32_t park_max_slots = 64;       ///< LDS slots of block_size elements each
-    uint32_t park_prefetch = 32;        ///< issue a reload this many nodes before its first use (< window)
+    bool park_in_lds = true;            ///< very long-lived values wait in LDS instead of AGPRs/scratch (GFHIP_PARK=0 disables)
+    uint32_t park_min_range = 1500;     ///< park values whose live range exceeds this many nodes ...
+    uint32_t park_window = 100;         ///< ... uses closer than this share one reload
+    uint32_t park_max_slots = 32;       ///< LDS slots of block_size elements each
+    uint32_t sched_barrier_every = 0;   ///< EXPERIMENT: __builtin_amdgcn_sched_barrier(0) every N nodes (0 = none)
+    uint32_t park_prefetch = 50;        ///< issue a reload this many nodes before its first use (< window)
 
 //  Environment overrides (they change the generated text, hence the cache key).
     static codegen_options from_environment() {
         codegen_options o;
         if (const char *e = std::getenv("GFHIP_DIVISION")) o.shared_reciprocal = std::string(e) != "ieee";
-        if (const char *e = std::getenv("GFHIP_PARK")) o.park_in_lds = std::string(e) == "1";
+        if (const char *e = std::getenv("GFHIP_PARK")) o.park_in_lds = std::string(e) != "0";
         if (const char *e = std::getenv("GFHIP_PARK_MIN_RANGE")) o.park_min_range = static_cast<uint32_t> (std::atoi(e));
         if (const char *e = std::getenv("GFHIP_PARK_WINDOW")) o.park_window = static_cast<uint32_t> (std::atoi(e));
+        if (const char *e = std::getenv("GFHIP_SCHED_BARRIER")) o.sched_barrier_every = static_cast<uint32_t> (std::atoi(e));
         if (const char *e = std::getenv("GFHIP_PARK_PREFETCH")) o.park_prefetch = static_cast<uint32_t> (std::atoi(e));
         if (const char *e = std::getenv("GFHIP_PARK_MAX_SLOTS")) o.park_max_slots = static_cast<uint32_t> (std::atoi(e));
         if (const char *e = std::getenv("GFHIP_COMPACT_TABLES")) o.compact_tables = std::string(e) != "0";
@@ -260,8 +262,10 @@ inline lowered lower(const item &it, const codegen_options &opt = codegen_option
     }
     out.block_size = opt.block_size;
 
-//  LDS parking (off by default: on MI355X it removes the scratch spills and 20 % of the AGPR
-//  moves but the ordered LDS reads cost more than they save — 0.46 ms vs 0.36 ms per step).
+//  LDS parking.  Measured on MI355X (1e6 rays, ms per RK4 step): none 0.359 (340 B/lane of
+//  scratch = 350 MB of HBM writes per step); every value with range > 300 nodes 0.46-0.55
+//  (each LDS op costs the single in-order wave an issue slot, like the move it replaces);
+//  only values with range > 1500 nodes, <= 32 slots: 0.317 and NO scratch — the default.
 //  The RK4 item keeps ~150 fp64 values alive (stage results, the state, shared
 //  sub-expressions of the seven partials); at 512 registers per lane the compiler shuttles
 //  them through AGPRs (two VALU moves each way) and scratch (HBM write traffic).  Values
@@ -420,8 +424,15 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
         if (park_slots) {
             //  volatile: no store-to-load forwarding (that would put the value back in a register);
 //  explicit LDS address space so the accesses stay ds_write_b64/ds_read_b64.
-            s << "    typedef volatile __attribute__((address_space(3))) real park_t;\n";
+//  Two laundered copies of the same LDS pointer: the compiler cannot prove that a read through
+//  `park_read` aliases a write through `park` (so no store-to-load forwarding, which would put
+//  the value back in a register) nor that it does not (so a read is never hoisted above an
+//  earlier write).  Not volatile: waits are placed at the first use, not after the read.
+            s << "    typedef __attribute__((address_space(3))) real park_t;\n";
             s << "    park_t *park = (park_t *)(lds_raw + " << park_offset << ") + threadIdx.x;\n";
+            s << "    park_t *park_read = park;\n";
+            s << "    asm volatile(\"\" : \"+v\"(park));\n";
+            s << "    asm volatile(\"\" : \"+v\"(park_read));\n";
         }
     }
 
@@ -485,13 +496,16 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
             if (found == reloads_at_position.end()) return;
             for (const uint32_t v : found->second) {
                 name[v] = "r" + std::to_string(v) + "p" + std::to_string(plan[v].reload_at[position]);
-                s << ind << "const real " << name[v] << " = park[" << plan[v].slot*out.block_size << "u];\n";
+                s << ind << "const real " << name[v] << " = park_read[" << plan[v].slot*out.block_size << "u];\n";
             }
         };
         auto N = [&] (const uint32_t v) -> const std::string & { return name[v]; };
         for (size_t i = 0; i < it.code.size(); i++) {
             const gfir_instruction &c = it.code[i];
             reload(i);
+            if (opt.sched_barrier_every && i && i%opt.sched_barrier_every == 0) {
+                s << ind << "__builtin_amdgcn_sched_barrier(0);\n";
+            }
             switch (c.op) {
                 case GFIR_CONST:
                     s << ind << "const real r" << i << " = " << literal(c.imm[0]) << ";\n";

@@ -142,3 +142,22 @@ def test_analytic_restatement_locates_the_reference_reducer_bug(efit_tables, gol
         np.testing.assert_allclose(dD[slot], ref[slot + 1], rtol=1.0e-6, atol=1.0e-9*s)
     relative = np.abs(dD[6] - ref[7])/np.maximum(np.abs(dD[6]), 1.0e-300)
     assert np.median(relative) > 1.0e-2                   # dD/dz: not a rounding difference
+
+
+def test_compiled_oracle_equals_interpreter():
+    """bench.py's cpu_baseline times the DAG compiled to C (oracle/gfir_to_c.py); it must be the
+    same arithmetic as the interpreter, bit for bit."""
+    from oracle import gfir_to_c
+    from conftest import random_plasma_state
+    state = random_plasma_state(96, seed=42)
+    for name, steps in (("solver_kernel_f64", 3), ("loss_kernel_kx_f64", 2), ("korc_step_f32", 4)):
+        interpreted, compiled = item(name), gfir_to_c.CompiledItem(os.path.join(WORKLOADS, name + ".gfir"))
+        if name.startswith("korc"):
+            base = [np.full(96, v, dtype=np.float32) for v in (1.7, 0.0, 0.0, 0.0, 9.9, 1.0, 10.0)]
+        else:
+            base = [state[k] for k in STATE]
+        a, b = [c.copy() for c in base], [c.copy() for c in base]
+        outs_a, _ = interpreted.run(a, steps=steps)
+        outs_b, _ = compiled.run(b, steps=steps, threads=3)
+        for x, y in zip(a + outs_a, b + outs_b):
+            np.testing.assert_array_equal(x, y)
