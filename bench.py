@@ -29,17 +29,45 @@ BYTES_PER_RAY_STEP_F64 = 128      # read 8 + write 8 (7 setters + residual) x 8 
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def cpu_baseline(target_seconds=15.0):
+def available_cores():
+    """Host threads this process may actually use: the affinity mask, capped by the cgroup CPU
+    quota when there is one (a container can see 256 CPUs and own 16)."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(float(quota)/float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
+def measured_traffic(kernel_name, rays):
+    """HBM bytes per launch from the committed PMC passes (profiles/r01_traffic.json: rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE run on this same command), if they are for this launch size."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    try:
+        with open(path) as f:
+            entry = json.load(f).get(kernel_name)
+    except (OSError, ValueError):
+        return None
+    if entry and entry.get("rays_per_launch") == rays:
+        return entry["traffic_bytes_per_launch"]
+    return None
+
+
+def cpu_baseline(target_seconds=12.0):
     """The CPU oracle timed on a bounded sample of the same workload: the solver_kernel DAG as
     the reference's cpu_context runs it (one compiled statement per node, serial loop per
     thread, contiguous shards; oracle/gfir_to_c.py, gcc -O2, strict IEEE), one thread per
     available core.  Falls back to the interpreter (oracle/gfir_interp.c) without gcc."""
     from oracle import gfir
     from graph_framework_amd.xrays import STATE, workload
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
+    cores = available_cores()
     state = dict(t=0.0, w=500.0, x=2.5, y=0.0, z=0.0, kx=-600.0, ky=0.0, kz=0.0)
     rays = 256*cores
     columns = [np.full(rays, state[k]) for k in STATE]
@@ -51,9 +79,13 @@ def cpu_baseline(target_seconds=15.0):
     except Exception:
         item = gfir.Item(workload("solver_kernel"))
         how = "interpreted by oracle/gfir_interp.c"
-    _, probe = item.run(columns, steps=2, threads=cores)
-    steps = int(max(2, min(2000, target_seconds/(probe/2.0))))
-    _, seconds = item.run(columns, steps=steps, threads=cores)
+    item.run(columns, steps=1, threads=cores)                       # warm: first touch, thread start
+    steps, seconds, chunk = 0, 0.0, 4
+    while seconds < target_seconds and steps < 20000:
+        _, took = item.run(columns, steps=chunk, threads=cores)
+        steps += chunk
+        seconds += took
+        chunk = min(chunk*2, 512)
     sample = ("%d rays x %d RK4 steps of the same solver_kernel DAG, strict IEEE, %s, %d threads (%.1f s)"
               % (rays, steps, how, cores, seconds))
     return rays*steps/seconds, cores, sample
@@ -153,10 +185,12 @@ def main():
                        "lds_bytes": int(info.lds_bytes), "scratch_bytes": int(info.scratch_bytes),
                        "code_object_from_cache": bool(info.from_cache)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved/HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved/HBM_PEAK_GBPS, "traffic": measured_traffic(info.name.decode(), n_local),
                          "kernel": info.name.decode(), "kernel_ms": kernel_ms, "launches": int(launches),
                          "algorithmic_bytes_per_launch": n_local*BYTES_PER_RAY_STEP_F64,
-                         "note": "kernel is FP64-VALU bound at the reference's op count (see DESIGN.md)"},
+                         "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r01_solver_kernel.md)",
+                         "note": "the kernel is FP64-VALU issue bound (7.8k vector instructions per ray-step, "
+                                 "VALU busy 76 % at one wave per SIMD), not HBM bound: see DESIGN.md section 3"},
             "value_with_sync_host": total*args.steps/(elapsed + sync_elapsed),
             "newton_iterations": solve.newton_iterations,
         }
