@@ -98,6 +98,9 @@ def main():
     parser.add_argument("--warmup", type=int, default=10)
     parser.add_argument("--rays-per-gpu", type=int, default=1000000)
     parser.add_argument("--no-cpu-baseline", action="store_true")
+    parser.add_argument("--distribution", choices=["bench", "cli"], default="bench",
+                        help="bench: identical rays of xrays_bench.cpp:62-71 (default, the metric's workload); "
+                             "cli: the incoherent example distribution of graph_driver/xrays.cpp (BASELINE configs[2])")
     args = parser.parse_args()
 
     import torch
@@ -121,9 +124,14 @@ def main():
                 data = f.read()
         items[name] = gfd.broadcast_bytes(data, 0)
 
-    state = dict(t=0.0, w=500.0, x=2.5, y=0.0, z=0.0, kx=-600.0, ky=0.0, kz=0.0)
-    solve = Rk4ColdPlasmaEfit({k: np.full(n_local, v) for k, v in state.items()},
-                              index=local_rank, stream=torch.cuda.current_stream().cuda_stream, items=items)
+    if args.distribution == "bench":
+        state = dict(t=0.0, w=500.0, x=2.5, y=0.0, z=0.0, kx=-600.0, ky=0.0, kz=0.0)
+        initial = {k: np.full(n_local, v) for k, v in state.items()}
+    else:
+        from graph_framework_amd.xrays import cli_distribution
+        initial = cli_distribution(n_local, seed=rank)
+    solve = Rk4ColdPlasmaEfit(initial, index=local_rank, stream=torch.cuda.current_stream().cuda_stream,
+                              items=items)
     solve.init("kx")
     solve.compile()
 
@@ -178,8 +186,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "xrays_bench cold-plasma RK4 solver_kernel on EFIT (efit.nc), identical rays "
-                                   "omega=500 x=2.5 kx=Newton(-600), dt=1e-3, fp64",
+            "config": {"workload": ("xrays_bench cold-plasma RK4 solver_kernel on EFIT (efit.nc), identical rays "
+                                    "omega=500 x=2.5 kx=Newton(-600), dt=1e-3, fp64") if args.distribution == "bench" else
+                                   ("xrays cold-plasma RK4 solver_kernel on EFIT (efit.nc), incoherent CLI example "
+                                    "distribution, dt=1e-3, fp64"),
                        "rays_per_gpu": n_local, "total_rays": total, "parallelism": "rays sharded x%d" % world,
                        "kernel_nodes": int(info.num_instructions), "vgprs": int(info.vgprs),
                        "lds_bytes": int(info.lds_bytes), "scratch_bytes": int(info.scratch_bytes),

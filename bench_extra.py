@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Secondary measurements (not the driver's contract; bench.py is): the other items of the hot
+path at BASELINE.json's sizes, each with HIP-event kernel time and its HBM-roofline fraction.
+
+    python bench_extra.py korc_f32 | korc_f64 | loss | cli | fused
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def korc(dtype, n=10000000, steps=200):
+    """BASELINE configs[4] on one GPU: xkorc push, 1e7 particles.  Algorithmic bytes per
+    particle-step: (7 reads + 7 writes) x 4 B = 56 (fp32) / 112 (fp64), SURVEY §8(d)."""
+    from graph_framework_amd import korc as gk
+    push = gk.Korc(dict(x=1.7, y=0.0, z=0.0, ux=0.0, uy=0.99, uz=0.1, gamma=np.zeros(n)), dtype)
+    push.compile()
+    push.pre_run()
+    for _ in range(10):
+        push.run()
+    push.work.context.enable_timing(True)
+    push.wait()
+    start = time.perf_counter()
+    for _ in range(steps):
+        push.run()
+    push.wait()
+    elapsed = time.perf_counter() - start
+    ms, launches = push.step_item.kernel.timing()
+    bytes_per = 56 if dtype == "f32" else 112
+    achieved = n*bytes_per/(ms*1.0e-3)/1.0e9
+    return {"workload": "xkorc step, %d particles, %s" % (n, dtype), "value": n*steps/elapsed,
+            "unit": "particle-steps/s", "kernel_ms": ms, "launches": int(launches),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved/8000.0}}
+
+
+def loss(n=1000000):
+    """Newton init of the benchmark: loss_kernel + device max per iteration (88 B per ray-iteration)."""
+    from graph_framework_amd.xrays import Rk4ColdPlasmaEfit
+    solve = Rk4ColdPlasmaEfit({k: np.full(n, v) for k, v in
+                               dict(t=0.0, w=500.0, x=2.5, y=0.0, z=0.0, kx=-600.0, ky=0.0, kz=0.0).items()})
+    solve.work.context.enable_timing(True)
+    start = time.perf_counter()
+    solve.init("kx")
+    elapsed = time.perf_counter() - start
+    ms, launches = solve.newton.kernel.timing()
+    achieved = n*80/(ms*1.0e-3)/1.0e9
+    return {"workload": "loss_kernel (Newton) 1e6 rays fp64", "iterations": solve.newton_iterations,
+            "init_seconds_including_build": elapsed, "kernel_ms": ms, "launches": int(launches),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved/8000.0,
+                         "note": "80 B per ray-iteration in the kernel (8 reads + 2 writes); +8 B re-read by the reduction"}}
+
+
+def fused(n=1000000, steps=200, per_launch=10):
+    """RK4 with `per_launch` steps fused into one launch (xrays_bench's SUB_STEPS = 10)."""
+    from graph_framework_amd.xrays import Rk4ColdPlasmaEfit
+    solve = Rk4ColdPlasmaEfit({k: np.full(n, v) for k, v in
+                               dict(t=0.0, w=500.0, x=2.5, y=0.0, z=0.0, kx=-600.0, ky=0.0, kz=0.0).items()})
+    solve.init("kx")
+    solve.compile()
+    solve.step(per_launch)
+    solve.work.wait()
+    start = time.perf_counter()
+    for _ in range(steps//per_launch):
+        solve.step(per_launch)
+    solve.work.wait()
+    elapsed = time.perf_counter() - start
+    return {"workload": "solver_kernel, %d steps per launch" % per_launch, "value": n*steps/elapsed, "unit": "ray-steps/s"}
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "korc_f32"
+    if what.startswith("korc"):
+        out = korc(what.split("_")[1])
+    elif what == "loss":
+        out = loss()
+    elif what == "fused":
+        out = fused()
+    else:
+        raise SystemExit("unknown workload")
+    print(json.dumps(out))

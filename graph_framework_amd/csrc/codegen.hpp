@@ -67,6 +67,7 @@ struct lowered {
     uint32_t block_size = 256;
     size_t lds_bytes = 0;
     uint32_t park_slots = 0;            ///< LDS slots used for parked values
+    uint32_t elements = 1;              ///< consecutive rays owned by one lane
     uint64_t hash = 0;
 };
 
@@ -81,6 +82,7 @@ struct codegen_options {
     uint32_t park_min_range = 1500;     ///< park values whose live range exceeds this many nodes ...
     uint32_t park_window = 100;         ///< ... uses closer than this share one reload
     uint32_t park_max_slots = 32;       ///< LDS slots of block_size elements each
+    uint32_t elements_per_lane = 0;     ///< rays per lane (0 = auto = 1; 2/4 = vector loads, GFHIP_ELEMENTS_PER_LANE)
     uint32_t sched_barrier_every = 0;   ///< EXPERIMENT: __builtin_amdgcn_sched_barrier(0) every N nodes (0 = none)
     uint32_t park_prefetch = 50;        ///< issue a reload this many nodes before its first use (< window)
 
@@ -91,6 +93,7 @@ struct codegen_options {
         if (const char *e = std::getenv("GFHIP_PARK")) o.park_in_lds = std::string(e) != "0";
         if (const char *e = std::getenv("GFHIP_PARK_MIN_RANGE")) o.park_min_range = static_cast<uint32_t> (std::atoi(e));
         if (const char *e = std::getenv("GFHIP_PARK_WINDOW")) o.park_window = static_cast<uint32_t> (std::atoi(e));
+        if (const char *e = std::getenv("GFHIP_ELEMENTS_PER_LANE")) o.elements_per_lane = static_cast<uint32_t> (std::atoi(e));
         if (const char *e = std::getenv("GFHIP_SCHED_BARRIER")) o.sched_barrier_every = static_cast<uint32_t> (std::atoi(e));
         if (const char *e = std::getenv("GFHIP_PARK_PREFETCH")) o.park_prefetch = static_cast<uint32_t> (std::atoi(e));
         if (const char *e = std::getenv("GFHIP_PARK_MAX_SLOTS")) o.park_max_slots = static_cast<uint32_t> (std::atoi(e));
@@ -262,6 +265,20 @@ inline lowered lower(const item &it, const codegen_options &opt = codegen_option
     }
     out.block_size = opt.block_size;
 
+//  Rays per lane.  A lane that owns ONE 4- or 8-byte element issues 4/8-byte loads; small
+//  items are HBM bound (xkorc step: 56 B and ~200 flops per particle) and want 16 B per lane
+//  per access, so a lane owns 4 (fp32) or 2 (fp64) CONSECUTIVE rays: vector loads/stores and
+//  2-4 independent instruction streams per lane.  Large items (the RK4 step) keep one ray per
+//  lane — they are register bound.
+    uint32_t elements = opt.elements_per_lane;
+    if (elements == 0) {
+//  Measured (MI355X, xkorc 1e7 particles, loss_kernel 1e6 rays): 2 or 4 rays per lane are
+//  not faster than 1 — these items are issue bound by their divisions, not by load width.
+        elements = 1;
+    }
+    if (elements != 1 && elements != 2 && elements != 4) elements = 1;
+    out.elements = elements;
+
 //  LDS parking.  Measured on MI355X (1e6 rays, ms per RK4 step): none 0.359 (340 B/lane of
 //  scratch = 350 MB of HBM writes per step); every value with range > 300 nodes 0.46-0.55
 //  (each LDS op costs the single in-order wave an issue slot, like the move it replaces);
@@ -286,7 +303,7 @@ inline lowered lower(const item &it, const codegen_options &opt = codegen_option
     const uint32_t slot_limit = lds_used < lds_capacity
                               ? static_cast<uint32_t> (std::min<size_t> (opt.park_max_slots, (lds_capacity - lds_used)/slot_bytes))
                               : 0;
-    if (opt.park_in_lds && slot_limit > 0) {
+    if (opt.park_in_lds && slot_limit > 0 && elements == 1) {
         std::vector<std::vector<size_t>> uses(node_count);
         auto arity = [] (const uint32_t op) -> int {
             switch (op) {
@@ -361,7 +378,27 @@ inline lowered lower(const item &it, const codegen_options &opt = codegen_option
       << it.code.size() << " nodes, " << it.tables.size() << " tables in " << out.packs.size() << " packs.\n";
     s << "#include <hip/hip_runtime.h>\n";
     s << "typedef " << real << " real;\n";
-    const bool use_shared = f64 && opt.shared_reciprocal;
+    const bool use_shared = opt.shared_reciprocal;
+    if (!f64) {
+        s << R"(
+// fp32 division as hipcc lowers it (denormals on): scale, r = rcp(d) + one Newton step,
+// q = n*r refined by two residual steps, a third residual folded in by div_fmas, un-scale,
+// fixup.  Shared per denominator like the fp64 form below; identical bits while no scaling is
+// needed (|d| in [2^-60, 2^60] is checked per pass; quotients below 2^-100 are not).
+__device__ __forceinline__ float gf_rcp(const float d) {
+    const float r = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+}
+__device__ __forceinline__ float gf_div(const float n, const float d, const float r) {
+    const float q0 = n*r;
+    const float e0 = __builtin_fmaf(-d, q0, n);
+    const float q1 = __builtin_fmaf(e0, r, q0);
+    const float e1 = __builtin_fmaf(-d, q1, n);
+    return __builtin_amdgcn_div_fixupf(__builtin_fmaf(e1, r, q1), d, n);
+}
+)";
+    }
     if (f64) {
         s << R"(
 // IEEE fp64 division as hipcc lowers it is: scale, r = rcp(d) refined by two Newton steps,
@@ -436,19 +473,49 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
         }
     }
 
-    s << "    for (unsigned long long i = blockIdx.x*static_cast<unsigned long long> (blockDim.x) + threadIdx.x; i < n;\n"
-      << "         i += gridDim.x*static_cast<unsigned long long> (blockDim.x)) {\n";
+    const uint32_t E = elements;
+    if (E > 1) {
+        s << "    typedef real vec_t __attribute__((ext_vector_type(" << E << ")));\n";
+        s << "    const bool aligned = ((0";
+        for (size_t i = 0; i < it.symbols.size(); i++) s << " | reinterpret_cast<unsigned long long> (in" << i << ")";
+        for (size_t o = 0; o < it.outputs.size(); o++) s << " | reinterpret_cast<unsigned long long> (out" << o << ")";
+        s << ") & " << (E*esize - 1) << "ull) == 0;\n";
+    }
+    s << "    const unsigned long long groups = (n + " << (E - 1) << "ull)/" << E << "ull;\n";
+    s << "    for (unsigned long long g = blockIdx.x*static_cast<unsigned long long> (blockDim.x) + threadIdx.x; g < groups;\n"
+      << "         g += gridDim.x*static_cast<unsigned long long> (blockDim.x)) {\n";
+    s << "        const unsigned long long i = g*" << E << "ull;\n";
+    if (E > 1) {
+        s << "        const bool full = aligned && i + " << E << "ull <= n;\n";
+    }
     for (size_t i = 0; i < it.symbols.size(); i++) {
         std::string symbol = it.symbols[i];
         for (auto &ch : symbol) {
             if (ch == '\\' || ch == '\n') ch = ' ';
         }
-        s << "        real v" << i << " = in" << i << "[i];  // " << symbol << "\n";
+        s << "        real v" << i << "[" << E << "];  // " << symbol << "\n";
+        if (E > 1) {
+            s << "        if (full) {\n"
+              << "            const vec_t t = *reinterpret_cast<const vec_t *> (in" << i << " + i);\n"
+              << "            for (unsigned int e = 0; e < " << E << "u; e++) v" << i << "[e] = t[e];\n"
+              << "        } else {\n"
+              << "            for (unsigned int e = 0; e < " << E << "u; e++) v" << i << "[e] = i + e < n ? in" << i << "[i + e] : " << literal(0.0) << ";\n"
+              << "        }\n";
+        } else {
+            s << "        v" << i << "[0] = in" << i << "[i];\n";
+        }
     }
     for (size_t o = 0; o < it.outputs.size(); o++) {
-        s << "        real o" << o << " = 0;\n";
+        s << "        real o" << o << "[" << E << "] = {};\n";
     }
     s << "        for (unsigned int step = 0; step < steps; step++) {\n";
+    if (E > 1) {
+        s << "            #pragma unroll\n";
+    }
+    s << "            for (unsigned int e = 0; e < " << E << "u; e++) {\n";
+    if (E > 1) {
+        s << "            if (i + e >= n) continue;\n";
+    }
     for (size_t k = 0; k < it.setters.size(); k++) {
         s << "            real sv" << k << ";\n";
     }
@@ -511,7 +578,7 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
                     s << ind << "const real r" << i << " = " << literal(c.imm[0]) << ";\n";
                     break;
                 case GFIR_INPUT:
-                    s << ind << "const real r" << i << " = v" << c.a << ";\n";
+                    s << ind << "const real r" << i << " = v" << c.a << "[e];\n";
                     break;
                 case GFIR_ADD:
                     s << ind << "const real r" << i << " = " << N(c.a) << " + " << N(c.b) << ";\n";
@@ -527,8 +594,8 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
                         if (!reciprocal_done[c.b]) {
                             reciprocal_done[c.b] = true;
                             s << ind << "const real q" << c.b << " = gf_rcp(" << N(c.b) << ");\n";
-                            s << ind << "dmax = __builtin_fmax(dmax, __builtin_fabs(" << N(c.b) << "));\n";
-                            s << ind << "dmin = __builtin_fmin(dmin, __builtin_fabs(" << N(c.b) << "));\n";
+                            s << ind << "dmax = __builtin_fmax" << sfx << "(dmax, __builtin_fabs" << sfx << "(" << N(c.b) << "));\n";
+                            s << ind << "dmin = __builtin_fmin" << sfx << "(dmin, __builtin_fabs" << sfx << "(" << N(c.b) << "));\n";
                         }
                         s << ind << "const real r" << i << " = gf_div(" << N(c.a) << ", " << N(c.b) << ", q" << c.b << ");\n";
                     } else {
@@ -632,13 +699,14 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
 //  results are then not guaranteed bit-identical and the item should be rebuilt with
 //  GFHIP_DIVISION=ieee.  Never observed on the hot-path workloads (|d| spans 1e-30..1e+30).
         s << "            bool bad = false;\n";
-        s << "            real dmax = 0x1p+0, dmin = 0x1p+0;   // extreme |denominator| of this pass\n";
+        s << "            real dmax = " << literal(1.0) << ", dmin = " << literal(1.0) << ";   // extreme |denominator| of this pass\n";
         s << "            {\n";
         emit_body(true);
         s << "                real finite_check = " << literal(0.0) << ";\n";
         for (size_t k = 0; k < it.setters.size(); k++) s << "                finite_check += sv" << k << ";\n";
         for (size_t o = 0; o < it.outputs.size(); o++) s << "                finite_check += so" << o << ";\n";
-        s << "                bad = !__builtin_isfinite(finite_check) || !(dmin >= 0x1p-500) || !(dmax <= 0x1p+500);\n";
+        s << "                bad = !__builtin_isfinite(finite_check) || !(dmin >= " << (f64 ? "0x1p-500" : "0x1p-60f")
+          << ") || !(dmax <= " << (f64 ? "0x1p+500" : "0x1p+60f") << ");\n";
         s << "            }\n";
         s << "            if (__builtin_expect(bad, 0)) atomicOr(flags, 1u);\n";
     } else {
@@ -647,20 +715,34 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
         s << "            }\n";
     }
     for (size_t o = 0; o < it.outputs.size(); o++) {
-        s << "            o" << o << " = so" << o << ";\n";
+        s << "            o" << o << "[e] = so" << o << ";\n";
     }
     for (size_t k = 0; k < it.setters.size(); k++) {
-        s << "            v" << it.setters[k].input << " = sv" << k << ";\n";
+        s << "            v" << it.setters[k].input << "[e] = sv" << k << ";\n";
     }
+    s << "            }\n";
     s << "        }\n";
 //  Stores: setters first, then outputs (cpu_context.hpp:522-580).
+    auto store = [&] (const std::string &pointer, const std::string &values) {
+        if (E > 1) {
+            s << "        if (full) {\n"
+              << "            vec_t t;\n"
+              << "            for (unsigned int e = 0; e < " << E << "u; e++) t[e] = " << values << "[e];\n"
+              << "            *reinterpret_cast<vec_t *> (" << pointer << " + i) = t;\n"
+              << "        } else {\n"
+              << "            for (unsigned int e = 0; e < " << E << "u; e++) if (i + e < n) " << pointer << "[i + e] = " << values << "[e];\n"
+              << "        }\n";
+        } else {
+            s << "        " << pointer << "[i] = " << values << "[0];\n";
+        }
+    };
     for (size_t i = 0; i < it.symbols.size(); i++) {
         if (out.input_written[i]) {
-            s << "        in" << i << "[i] = v" << i << ";\n";
+            store("in" + std::to_string(i), "v" + std::to_string(i));
         }
     }
     for (size_t o = 0; o < it.outputs.size(); o++) {
-        s << "        out" << o << "[i] = o" << o << ";\n";
+        store("out" + std::to_string(o), "o" + std::to_string(o));
     }
     s << "    }\n}\n";
 

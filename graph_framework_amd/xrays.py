@@ -35,6 +35,25 @@ def shard_bounds(total, shards, index):
     return begin, begin + batch + (1 if extra > index else 0)
 
 
+def cli_distribution(num_rays, seed=0, dtype="f64"):
+    """The incoherent initial conditions of the xrays CLI example (graph_driver/xrays.cpp:392-399,
+    :448-453; graph_driver/CMakeLists.txt:5-31): cylindrical r = 2.5, phi ~ N(0, 0.05),
+    z ~ N(0, 0.05), ky ~ N(-100, 10), kz ~ N(0, 10), omega ~ N(700, 10), kx guess -700 (then
+    Newton), seed = shard index.  The reference draws with std::mt19937_64 +
+    std::normal_distribution (libstdc++-specific); this generator keeps the distributions and
+    the per-shard seeding but draws with numpy's PCG64, so the samples differ."""
+    rng = np.random.default_rng(seed)
+    np_dtype = _NP[dtype]
+    w = rng.normal(700.0, 10.0, num_rays)
+    kx = np.full(num_rays, -700.0)
+    ky = rng.normal(-100.0, 10.0, num_rays)
+    kz = rng.normal(0.0, 10.0, num_rays)
+    z = rng.normal(0.0, 0.05, num_rays)
+    phi = rng.normal(0.0, 0.05, num_rays)
+    state = dict(t=np.zeros(num_rays), w=w, x=2.5*np.cos(phi), y=2.5*np.sin(phi), z=z, kx=kx, ky=ky, kz=kz)
+    return {k: np.ascontiguousarray(v, dtype=np_dtype) for k, v in state.items()}
+
+
 class Rk4ColdPlasmaEfit:
     """solver::rk4<dispersion::cold_plasma<T>> on an EFIT equilibrium."""
 
