@@ -39,15 +39,20 @@ def korc(dtype, n=10000000, steps=200):
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved/8000.0}}
 
 
-def loss(n=1000000):
-    """Newton init of the benchmark: loss_kernel + device max per iteration (88 B per ray-iteration)."""
+def loss(n=1000000, per_ray=False):
+    """Newton init of the benchmark: loss_kernel + device max per iteration (88 B per ray-iteration),
+    or (per_ray) the whole loop inside one launch."""
     from graph_framework_amd.xrays import Rk4ColdPlasmaEfit
     solve = Rk4ColdPlasmaEfit({k: np.full(n, v) for k, v in
                                dict(t=0.0, w=500.0, x=2.5, y=0.0, z=0.0, kx=-600.0, ky=0.0, kz=0.0).items()})
     solve.work.context.enable_timing(True)
+    solve.work.context.wait()
     start = time.perf_counter()
-    solve.init("kx")
+    solve.init("kx", per_ray=per_ray)
     elapsed = time.perf_counter() - start
+    if per_ray:
+        return {"workload": "Newton init, per-ray loop in one launch, 1e6 rays fp64",
+                "iterations": solve.newton_iterations, "init_seconds_including_build": elapsed}
     ms, launches = solve.newton.kernel.timing()
     achieved = n*80/(ms*1.0e-3)/1.0e9
     return {"workload": "loss_kernel (Newton) 1e6 rays fp64", "iterations": solve.newton_iterations,
@@ -79,6 +84,8 @@ if __name__ == "__main__":
         out = korc(what.split("_")[1])
     elif what == "loss":
         out = loss()
+    elif what == "loss_per_ray":
+        out = loss(per_ray=True)
     elif what == "fused":
         out = fused()
     else:

@@ -42,6 +42,7 @@ SYMBOLS = [
     ("gfhip_run", _I, [_P, _U32]),
     ("gfhip_run_max", _I, [_P, ctypes.POINTER(ctypes.c_double)]),
     ("gfhip_converge", _I, [_P, ctypes.c_double, _S, ctypes.POINTER(_S), ctypes.POINTER(ctypes.c_double)]),
+    ("gfhip_converge_per_ray", _I, [_P, ctypes.c_double, _S, ctypes.POINTER(_S), ctypes.POINTER(ctypes.c_double)]),
     ("gfhip_wait", _I, [_P]),
     ("gfhip_get_flags", _I, [_P, ctypes.POINTER(ctypes.c_uint32)]),
     ("gfhip_copy_to_device", _I, [_P, _U64, _P]),

@@ -172,6 +172,15 @@ class Kernel:
                                                     ctypes.byref(iterations), ctypes.byref(last)))
         return iterations.value, last.value
 
+    def converge_per_ray(self, tolerance=1.0e-30, max_iterations=1000):
+        """The converge loop per ray inside one launch (wavefront ballot exit).
+        Returns (max iterations over rays, max final residual)."""
+        iterations = ctypes.c_size_t()
+        last = ctypes.c_double()
+        self.context._check(self.lib.gfhip_converge_per_ray(self.handle, float(tolerance), int(max_iterations),
+                                                            ctypes.byref(iterations), ctypes.byref(last)))
+        return iterations.value, last.value
+
     def timing(self):
         """(average launch ms, launches) since the last call; needs Context.enable_timing()."""
         ms = ctypes.c_double()

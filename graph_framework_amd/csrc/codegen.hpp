@@ -68,6 +68,7 @@ struct lowered {
     size_t lds_bytes = 0;
     uint32_t park_slots = 0;            ///< LDS slots used for parked values
     uint32_t elements = 1;              ///< consecutive rays owned by one lane
+    bool has_converge = false;          ///< the module also holds `<name>_converge`
     uint64_t hash = 0;
 };
 
@@ -431,9 +432,19 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
 }
 )";
     }
+//  Two entry points per item: `<name>` runs `steps` passes; `<name>_converge` (items with a
+//  setter and an output, one ray per lane) runs the stall loop of workflow.hpp:179-205 PER RAY
+//  inside the launch — every lane iterates on its own residual, a wavefront leaves the loop
+//  when the ballot of still-active lanes is empty.  That is the reference's converge loop
+//  applied to each ray as its own shard; it equals the reference's global-max loop when the
+//  rays are identical (the benchmark) and is offered as gfhip_converge_per_ray.
+    const bool has_converge = !it.setters.empty() && !it.outputs.empty() && elements == 1 &&
+                              it.code.size() <= 1500;
+    out.has_converge = has_converge;
+    auto emit_kernel = [&] (const bool converge) {
     s << "extern \"C\" __global__ void __launch_bounds__(" << out.block_size;
     if (opt.waves_per_simd) s << ", " << opt.waves_per_simd;
-    s << ")\n" << out.kernel_name << "(";
+    s << ")\n" << out.kernel_name << (converge ? "_converge" : "") << "(";
     for (size_t i = 0; i < it.symbols.size(); i++) {
         s << (out.input_written[i] ? "" : "const ") << "real *__restrict__ in" << i << ", ";
     }
@@ -443,7 +454,12 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
     for (size_t p = 0; p < out.packs.size(); p++) {
         s << "const real *__restrict__ pack" << p << ", ";
     }
-    s << "unsigned int *__restrict__ flags, const unsigned long long n, const unsigned int steps) {\n";
+    if (converge) {
+        s << "unsigned int *__restrict__ flags, const unsigned long long n, const real tolerance,\n"
+          << "        const unsigned int max_iterations, unsigned int *__restrict__ iterations) {\n";
+    } else {
+        s << "unsigned int *__restrict__ flags, const unsigned long long n, const unsigned int steps) {\n";
+    }
 
 //  LDS staging.
     if (lds_used) {
@@ -508,13 +524,22 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
     for (size_t o = 0; o < it.outputs.size(); o++) {
         s << "        real o" << o << "[" << E << "] = {};\n";
     }
-    s << "        for (unsigned int step = 0; step < steps; step++) {\n";
-    if (E > 1) {
-        s << "            #pragma unroll\n";
-    }
-    s << "            for (unsigned int e = 0; e < " << E << "u; e++) {\n";
-    if (E > 1) {
-        s << "            if (i + e >= n) continue;\n";
+    if (converge) {
+        s << "        unsigned int count = 0;\n"
+          << "        bool active = true;\n"
+          << "        real last_max = " << (f64 ? "__DBL_MAX__" : "__FLT_MAX__") << ", off_last_max = last_max;\n"
+          << "        for (;;) {\n"
+          << "            if (active) {\n"
+          << "            const unsigned int e = 0;\n";
+    } else {
+        s << "        for (unsigned int step = 0; step < steps; step++) {\n";
+        if (E > 1) {
+            s << "            #pragma unroll\n";
+        }
+        s << "            for (unsigned int e = 0; e < " << E << "u; e++) {\n";
+        if (E > 1) {
+            s << "            if (i + e >= n) continue;\n";
+        }
     }
     for (size_t k = 0; k < it.setters.size(); k++) {
         s << "            real sv" << k << ";\n";
@@ -720,8 +745,24 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
     for (size_t k = 0; k < it.setters.size(); k++) {
         s << "            v" << it.setters[k].input << "[e] = sv" << k << ";\n";
     }
-    s << "            }\n";
-    s << "        }\n";
+    if (converge) {
+//  converge_item::run for this ray:  while (A && B && C && iterations++ < max) {...}
+        const std::string fabs_ = std::string("__builtin_fabs") + (f64 ? "" : "f");
+        s << "            const real residual = so" << it.outputs.size() - 1 << ";\n"
+          << "            bool go = " << fabs_ << "(residual) > " << fabs_ << "(tolerance) &&\n"
+          << "                      " << fabs_ << "(last_max - residual) > " << fabs_ << "(tolerance) &&\n"
+          << "                      " << fabs_ << "(off_last_max - residual) > " << fabs_ << "(tolerance);\n"
+          << "            if (go) { go = count < max_iterations; count++; }\n"
+          << "            if (go) { last_max = residual; if (!(count%2u)) off_last_max = residual; }\n"
+          << "            active = go;\n"
+          << "            }\n"
+          << "            if (__ballot(active) == 0ull) break;   // the whole wavefront has stalled\n"
+          << "        }\n"
+          << "        atomicMax(iterations, count);\n";
+    } else {
+        s << "            }\n";
+        s << "        }\n";
+    }
 //  Stores: setters first, then outputs (cpu_context.hpp:522-580).
     auto store = [&] (const std::string &pointer, const std::string &values) {
         if (E > 1) {
@@ -745,6 +786,11 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
         store("out" + std::to_string(o), "o" + std::to_string(o));
     }
     s << "    }\n}\n";
+    };
+    emit_kernel(false);
+    if (has_converge) {
+        emit_kernel(true);
+    }
 
     out.source = s.str();
     out.hash = fnv1a(out.source + "|" + compile_flags());

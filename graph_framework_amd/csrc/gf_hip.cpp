@@ -107,6 +107,7 @@ struct gfhip_kernel {
     size_t num_rays = 0;
     hipModule_t module = nullptr;
     hipFunction_t function = nullptr;
+    hipFunction_t converge_function = nullptr;
     bool from_cache = false;
     std::vector<void *> pack_device;
     std::vector<uint64_t> input_keys, output_keys;
@@ -282,6 +283,10 @@ static int build_kernel(gfhip_context *ctx, gfhip_kernel *k) {
 
     GFHIP_TRY(ctx, hipModuleLoadData(&k->module, code.data()), "hipModuleLoadData");
     GFHIP_TRY(ctx, hipModuleGetFunction(&k->function, k->module, k->low.kernel_name.c_str()), "hipModuleGetFunction");
+    if (k->low.has_converge) {
+        GFHIP_TRY(ctx, hipModuleGetFunction(&k->converge_function, k->module, (k->low.kernel_name + "_converge").c_str()),
+                  "hipModuleGetFunction(converge)");
+    }
     (void)hipFuncGetAttribute(&k->vgprs, HIP_FUNC_ATTRIBUTE_NUM_REGS, k->function);
     (void)hipFuncGetAttribute(&k->lds_static, HIP_FUNC_ATTRIBUTE_SHARED_SIZE_BYTES, k->function);
     (void)hipFuncGetAttribute(&k->scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, k->function);
@@ -527,6 +532,60 @@ static int check_flags(gfhip_context *ctx) {
         std::fprintf(stderr, "graph_framework_amd: a denominator left [2^-500, 2^500] or a result is not finite; "
                              "fp64 quotients are no longer guaranteed bit-identical to IEEE division. "
                              "Rebuild with GFHIP_DIVISION=ieee for the exact sequence.\n");
+    }
+    return 0;
+}
+
+//  Per-ray converge loop inside one launch (`<name>_converge`, see codegen.hpp).
+extern "C" int gfhip_converge_per_ray(gfhip_kernel *k, double tolerance, size_t max_iterations,
+                                      size_t *iterations, double *last_max) {
+    if (!k) return 1;
+    gfhip_context *ctx = k->ctx;
+    GFHIP_TRY(ctx, hipSetDevice(ctx->device), "hipSetDevice");
+    if (!k->function) return ctx->fail("kernel has not been compiled (gfhip_compile)");
+    if (!k->converge_function) return ctx->fail("item has no setter/output to converge on");
+    if (!k->bound) return ctx->fail("kernel arguments are not bound (gfhip_create_kernel_call)");
+    if (k->num_rays == 0) {
+        if (iterations) *iterations = 0;
+        if (last_max) *last_max = -std::numeric_limits<double>::infinity();
+        return 0;
+    }
+    std::vector<void *> pointers;
+    for (auto key : k->input_keys) pointers.push_back(ctx->buffers[key].pointer);
+    for (auto key : k->output_keys) pointers.push_back(ctx->buffers[key].pointer);
+    for (void *p : k->pack_device) pointers.push_back(p);
+    pointers.push_back(ctx->device_flags);
+    unsigned long long n = k->num_rays;
+    double tolerance64 = tolerance;
+    float tolerance32 = static_cast<float> (tolerance);
+    unsigned int maximum = static_cast<unsigned int> (max_iterations > 0xFFFFFFFEull ? 0xFFFFFFFEull : max_iterations);
+//  The iteration counter shares the 8-byte reduction scalar (low word).
+    unsigned int *counter = reinterpret_cast<unsigned int *> (ctx->device_scalar);
+    GFHIP_TRY(ctx, hipMemsetAsync(ctx->device_scalar, 0, sizeof(unsigned long long), ctx->stream), "hipMemsetAsync");
+    std::vector<void *> params;
+    for (auto &p : pointers) params.push_back(&p);
+    params.push_back(&n);
+    params.push_back(k->item.dtype == GFIR_F64 ? static_cast<void *> (&tolerance64) : static_cast<void *> (&tolerance32));
+    params.push_back(&maximum);
+    params.push_back(&counter);
+    GFHIP_TRY(ctx, hipModuleLaunchKernel(k->converge_function, k->grid, 1, 1, k->low.block_size, 1, 1,
+                                         static_cast<unsigned int> (k->low.lds_bytes), ctx->stream,
+                                         params.data(), nullptr), "hipModuleLaunchKernel(converge)");
+    unsigned int used = 0;
+    GFHIP_TRY(ctx, hipMemcpyAsync(ctx->host_scalar, ctx->device_scalar, sizeof(unsigned long long),
+                                  hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
+    GFHIP_TRY(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    used = static_cast<unsigned int> (*ctx->host_scalar & 0xFFFFFFFFull);
+    if (iterations) *iterations = used;
+    if (last_max) {
+        const buffer &b = ctx->buffers[k->output_keys.back()];
+        GFHIP_TRY(ctx, hipMemsetAsync(ctx->device_scalar, 0, sizeof(unsigned long long), ctx->stream), "hipMemsetAsync");
+        gfhip::launch_max_reduce(b.pointer, k->num_rays, k->item.dtype == GFIR_F64, ctx->device_scalar,
+                                 ctx->num_cus, ctx->stream);
+        GFHIP_TRY(ctx, hipMemcpyAsync(ctx->host_scalar, ctx->device_scalar, sizeof(unsigned long long),
+                                      hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
+        GFHIP_TRY(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+        *last_max = decode_ordered(*ctx->host_scalar, k->item.dtype == GFIR_F64);
     }
     return 0;
 }

@@ -83,17 +83,22 @@ class Rk4ColdPlasmaEfit:
     def _initial(self):
         return {self.prefix + k: self.host[k] for k in STATE}
 
-    def init(self, variable="kx", tolerance=1.0e-30, max_iterations=1000):
+    def init(self, variable="kx", tolerance=1.0e-30, max_iterations=1000, per_ray=False):
         """solver_interface::init(x) (solver.hpp:254-274) -> dispersion_interface::solve
         (dispersion.hpp:1452-1475): its own manager in the reference, its own converge item
-        here; the solved variable is copied back to the host array."""
+        here; the solved variable is copied back to the host array.
+        per_ray=True runs the stall loop per ray inside ONE launch (wavefront ballot exit)
+        instead of the reference's kernel + global max + host test per iteration."""
         work = self.work
         item = work.add_converge_item(self._item("loss_kernel_" + variable), self.keys,
                                       [self.prefix + "newton_residual"], self.num_rays, self._initial(),
                                       tolerance, max_iterations)
         work.context.compile()
         item.create_kernel_call()
-        item.run()
+        if per_ray:
+            item.iterations, item.last_max = item.kernel.converge_per_ray(tolerance, max_iterations)
+        else:
+            item.run()
         self.newton = item
         self.newton_iterations, self.newton_last_max = item.iterations, item.last_max
         work.copy_to_host(self.prefix + variable, self.host[variable])

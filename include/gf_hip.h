@@ -95,6 +95,15 @@ int gfhip_run_max(gfhip_kernel *kernel, double *max_value);
 int gfhip_converge(gfhip_kernel *kernel, double tolerance, size_t max_iterations,
                    size_t *iterations, double *last_max);
 
+/* The same stall loop run PER RAY inside one launch: each lane iterates on its own residual
+ * and a wavefront leaves the loop when the ballot of active lanes is empty.  This is the
+ * reference loop applied to every ray as its own shard: identical to gfhip_converge when the
+ * rays are identical (the benchmark), otherwise rays stop as soon as they have stalled
+ * instead of iterating until the slowest ray of the shard has.  `iterations` receives the
+ * maximum over rays, `last_max` the maximum final residual. */
+int gfhip_converge_per_ray(gfhip_kernel *kernel, double tolerance, size_t max_iterations,
+                           size_t *iterations, double *last_max);
+
 /* Drain the stream.  Replaces  void wait()  (cuda_context.hpp:581-584). */
 int gfhip_wait(gfhip_context *ctx);
 
