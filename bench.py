@@ -98,6 +98,11 @@ def main():
     parser.add_argument("--warmup", type=int, default=10)
     parser.add_argument("--rays-per-gpu", type=int, default=1000000)
     parser.add_argument("--no-cpu-baseline", action="store_true")
+    parser.add_argument("--backend", choices=["nccl", "gloo"], default=None,
+                        help="torch.distributed backend (default nccl = RCCL); gloo + --share-gpu rehearses "
+                             "the multi-rank path on a one-GPU box")
+    parser.add_argument("--share-gpu", action="store_true",
+                        help="rehearsal only: every rank uses device 0")
     parser.add_argument("--distribution", choices=["bench", "cli"], default="bench",
                         help="bench: identical rays of xrays_bench.cpp:62-71 (default, the metric's workload); "
                              "cli: the incoherent example distribution of graph_driver/xrays.cpp (BASELINE configs[2])")
@@ -107,9 +112,11 @@ def main():
     from graph_framework_amd import distributed as gfd
     from graph_framework_amd.xrays import Rk4ColdPlasmaEfit, STATE, workload
 
-    rank, world, local_rank = gfd.init()
+    rank, world, local_rank = gfd.init(args.backend, device_index=0 if args.share_gpu else None)
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
 
     n_local = args.rays_per_gpu
@@ -159,15 +166,15 @@ def main():
 #  Output-cadence collective: all-gather of the trajectory state over xGMI (not in the step loop).
     gather_seconds = None
     if world > 1:
-        device_state = torch.from_numpy(host["x"]).cuda()
+        on_device = torch.distributed.get_backend() == "nccl"
+        shards = {k: (torch.from_numpy(host[k]).cuda() if on_device else torch.from_numpy(host[k])) for k in STATE}
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for k in STATE:
-            full = gfd.all_gather_shards(torch.from_numpy(host[k]).cuda(), total)
+            full = gfd.all_gather_shards(shards[k], total)
             assert full.numel() == total
         torch.cuda.synchronize()
         gather_seconds = gfd.max_over_ranks(time.perf_counter() - t0)
-        del device_state
 
     if rank == 0:
         info = solve.solver.kernel.info()

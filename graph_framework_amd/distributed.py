@@ -17,8 +17,9 @@ import numpy as np
 from .xrays import shard_bounds
 
 
-def init(backend=None):
-    """Initialise torch.distributed from the torchrun environment.  Returns (rank, world, local_rank)."""
+def init(backend=None, device_index=None):
+    """Initialise torch.distributed from the torchrun environment.  Returns (rank, world, local_rank).
+    device_index overrides LOCAL_RANK as the CUDA device (rehearsals on a one-GPU box)."""
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -30,7 +31,7 @@ def init(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(local_rank if device_index is None else device_index)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
 
