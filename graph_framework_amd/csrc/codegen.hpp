@@ -475,8 +475,7 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
         }
         s << "    __syncthreads();\n";
         if (park_slots) {
-            //  volatile: no store-to-load forwarding (that would put the value back in a register);
-//  explicit LDS address space so the accesses stay ds_write_b64/ds_read_b64.
+//  Explicit LDS address space so the accesses stay ds_write_b64/ds_read_b64.
 //  Two laundered copies of the same LDS pointer: the compiler cannot prove that a read through
 //  `park_read` aliases a write through `park` (so no store-to-load forwarding, which would put
 //  the value back in a register) nor that it does not (so a read is never hoisted above an

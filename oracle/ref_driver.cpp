@@ -535,6 +535,26 @@ static int cmd_export(const raw_tables &raw, const std::string dir, const double
     return 0;
 }
 
+//  export_misc <dir> <suffix>: small items that exercise every remaining node type the way
+//  graph_tests/jit_test.cpp, math_test.cpp, trigonometry_test.cpp and workflow_test.cpp:20-71 do
+//  (transcendentals, general pow, setters that alias their own inputs).
+template<typename T>
+static int cmd_export_misc(const std::string dir, const std::string suffix) {
+    auto a = graph::variable<T> (1, "a");
+    auto b = graph::variable<T> (1, "b");
+    auto c = graph::variable<T> (1, "c");
+    work_item<T> math({a, b, c},
+                      {graph::sin(a)*graph::cos(b), graph::atan(a, b), graph::exp(c/10.0),
+                       graph::log(a*a + 1.0), graph::pow(a*a + 1.0, b), graph::sqrt(a*a + b*b)/(c*c + 2.0),
+                       graph::fma(a, b, c)}, {});
+    math.write_gfir("math_kernel", dir + "/misc_math_kernel_" + suffix + ".gfir");
+//  workflow_test.cpp:20-71: x <- x + 1 style setters, an output of the OLD values, a swap.
+    work_item<T> alias({a, b, c}, {a + b + c},
+                       {{a + 1.0, a}, {a*b, b}, {graph::sqrt(c*c) + a, c}});
+    alias.write_gfir("alias_kernel", dir + "/misc_alias_kernel_" + suffix + ".gfir");
+    return 0;
+}
+
 template<typename T>
 static int dispatch(const raw_tables &raw, int argc, char **argv) {
     const std::string cmd = argv[3];
@@ -557,6 +577,8 @@ static int dispatch(const raw_tables &raw, int argc, char **argv) {
     } else if (cmd == "trace" && argc == 10) {
         return cmd_trace<T> (raw, argv[4], argv[5], atof(argv[6]), strtoull(argv[7], nullptr, 10),
                              strtoull(argv[8], nullptr, 10), atoi(argv[9]));
+    } else if (cmd == "export_misc" && argc == 6) {
+        return cmd_export_misc<T> (argv[4], argv[5]);
     } else if (cmd == "export_korc" && argc == 6) {
         return cmd_export_korc<T> (raw, argv[4], argv[5]);
     } else if (cmd == "korc" && argc == 8) {

@@ -49,6 +49,9 @@ def main():
     for name in ("loss_kernel_w", "loss_kernel_ky", "loss_kernel_kz", "dispersion_kernel", "efit_test_kernel"):
         os.remove(os.path.join(workloads, name + "_f32.gfir"))
 
+    for dtype in ("f64", "f32"):
+        subprocess.check_call([ref.BINARY, R.tables, dtype, "export_misc", workloads, dtype])
+
 #  xrays_bench ray.
     records, info = R.trace(bench_state(1), 1.0e-3, 1000, 1, 1)
     keep = [0, 1, 10, 100, 500, 1000]
