@@ -84,6 +84,7 @@ struct codegen_options {
     uint32_t park_window = 100;         ///< ... uses closer than this share one reload
     uint32_t park_max_slots = 32;       ///< LDS slots of block_size elements each
     uint32_t elements_per_lane = 0;     ///< rays per lane (0 = auto = 1; 2/4 = vector loads, GFHIP_ELEMENTS_PER_LANE)
+    bool prefetch_next_tile = false;    ///< EXPERIMENT: load the next grid-stride tile's inputs before computing this one
     uint32_t sched_barrier_every = 0;   ///< EXPERIMENT: __builtin_amdgcn_sched_barrier(0) every N nodes (0 = none)
     uint32_t park_prefetch = 50;        ///< issue a reload this many nodes before its first use (< window)
 
@@ -95,6 +96,7 @@ struct codegen_options {
         if (const char *e = std::getenv("GFHIP_PARK_MIN_RANGE")) o.park_min_range = static_cast<uint32_t> (std::atoi(e));
         if (const char *e = std::getenv("GFHIP_PARK_WINDOW")) o.park_window = static_cast<uint32_t> (std::atoi(e));
         if (const char *e = std::getenv("GFHIP_ELEMENTS_PER_LANE")) o.elements_per_lane = static_cast<uint32_t> (std::atoi(e));
+        if (const char *e = std::getenv("GFHIP_PREFETCH_NEXT")) o.prefetch_next_tile = std::string(e) == "1";
         if (const char *e = std::getenv("GFHIP_SCHED_BARRIER")) o.sched_barrier_every = static_cast<uint32_t> (std::atoi(e));
         if (const char *e = std::getenv("GFHIP_PARK_PREFETCH")) o.park_prefetch = static_cast<uint32_t> (std::atoi(e));
         if (const char *e = std::getenv("GFHIP_PARK_MAX_SLOTS")) o.park_max_slots = static_cast<uint32_t> (std::atoi(e));
@@ -497,8 +499,20 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
         s << ") & " << (E*esize - 1) << "ull) == 0;\n";
     }
     s << "    const unsigned long long groups = (n + " << (E - 1) << "ull)/" << E << "ull;\n";
-    s << "    for (unsigned long long g = blockIdx.x*static_cast<unsigned long long> (blockDim.x) + threadIdx.x; g < groups;\n"
-      << "         g += gridDim.x*static_cast<unsigned long long> (blockDim.x)) {\n";
+    const bool prefetch = opt.prefetch_next_tile && E == 1 && !converge;
+    if (prefetch) {
+//  Software pipelining across grid-stride tiles: at one wave per SIMD nothing else hides the
+//  HBM latency of a tile's first loads, so they are issued one tile ahead.
+        s << "    const unsigned long long stride = gridDim.x*static_cast<unsigned long long> (blockDim.x);\n";
+        s << "    unsigned long long g = blockIdx.x*static_cast<unsigned long long> (blockDim.x) + threadIdx.x;\n";
+        for (size_t i = 0; i < it.symbols.size(); i++) {
+            s << "    real next" << i << " = g < groups ? in" << i << "[g] : " << literal(0.0) << ";\n";
+        }
+        s << "    for (; g < groups; g += stride) {\n";
+    } else {
+        s << "    for (unsigned long long g = blockIdx.x*static_cast<unsigned long long> (blockDim.x) + threadIdx.x; g < groups;\n"
+          << "         g += gridDim.x*static_cast<unsigned long long> (blockDim.x)) {\n";
+    }
     s << "        const unsigned long long i = g*" << E << "ull;\n";
     if (E > 1) {
         s << "        const bool full = aligned && i + " << E << "ull <= n;\n";
@@ -516,8 +530,15 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
               << "        } else {\n"
               << "            for (unsigned int e = 0; e < " << E << "u; e++) v" << i << "[e] = i + e < n ? in" << i << "[i + e] : " << literal(0.0) << ";\n"
               << "        }\n";
+        } else if (prefetch) {
+            s << "        v" << i << "[0] = next" << i << ";\n";
         } else {
             s << "        v" << i << "[0] = in" << i << "[i];\n";
+        }
+    }
+    if (prefetch) {
+        for (size_t i = 0; i < it.symbols.size(); i++) {
+            s << "        if (g + stride < groups) next" << i << " = in" << i << "[g + stride];\n";
         }
     }
     for (size_t o = 0; o < it.outputs.size(); o++) {

@@ -323,10 +323,17 @@ static int build_kernel(gfhip_context *ctx, gfhip_kernel *k) {
     const size_t groups = (k->num_rays + k->low.elements - 1)/k->low.elements;
     size_t want = (groups + block - 1)/block;
     if (want < 1) want = 1;
-//  Grid-stride over at most 16 workgroups per CU.  Measured on the fp64 push (1e7 particles):
-//  exact grid (39063 workgroups) 0.276 ms, 64/CU 0.245, 16/CU 0.235; fp32 push and loss_kernel
-//  are flat; the RK4 kernel at 1e6 rays (3907 workgroups) is below the cap.
-    size_t cap = static_cast<size_t> (ctx->num_cus)*16;
+//  Persistent-style grid: a few workgroups per resident slot, the kernel grid-strides.
+//  Measured (1e7-particle fp64 push): exact grid 0.276 ms, 64 per CU 0.245, 16 per CU 0.235.
+//  Register-bound items that fit one workgroup per CU (the RK4 kernel: 507 registers, one wave
+//  per SIMD) run best with exactly one workgroup per CU: 0.279 vs 0.298 ms per step at 1e6
+//  rays (the coefficient packs are staged into LDS once per workgroup instead of 15 times).
+    int resident = 0;
+    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&resident, k->function, static_cast<int> (block),
+                                                           k->low.lds_bytes) != hipSuccess || resident < 1) {
+        resident = 1;
+    }
+    size_t cap = static_cast<size_t> (ctx->num_cus)*static_cast<size_t> (resident)*(resident == 1 ? 1 : 4);
     if (const char *env = std::getenv("GFHIP_GRID_PER_CU")) {
         cap = static_cast<size_t> (ctx->num_cus)*static_cast<size_t> (std::atoi(env));
     }
