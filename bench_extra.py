@@ -61,6 +61,33 @@ def loss(n=1000000, per_ray=False):
                          "note": "80 B per ray-iteration in the kernel (8 reads + 2 writes); +8 B re-read by the reduction"}}
 
 
+def solver_f32(n=1000000, steps=200):
+    """The same RK4 item in fp32 (the reference benchmarks float as well, xrays_bench.cpp:124-135;
+    its published A100 figure is fp32).  64 B per ray-step."""
+    from graph_framework_amd.xrays import Rk4ColdPlasmaEfit
+    solve = Rk4ColdPlasmaEfit({k: np.full(n, v) for k, v in
+                               dict(t=0.0, w=500.0, x=2.5, y=0.0, z=0.0, kx=-600.0, ky=0.0, kz=0.0).items()},
+                              dtype="f32")
+    solve.init("kx")
+    solve.compile()
+    for _ in range(10):
+        solve.step()
+    solve.work.context.enable_timing(True)
+    solve.work.wait()
+    start = time.perf_counter()
+    for _ in range(steps):
+        solve.step()
+    solve.work.wait()
+    elapsed = time.perf_counter() - start
+    ms, launches = solve.solver.kernel.timing()
+    info = solve.solver.kernel.info()
+    achieved = n*64/(ms*1.0e-3)/1.0e9
+    return {"workload": "solver_kernel fp32, %d rays" % n, "value": n*steps/elapsed, "unit": "ray-steps/s",
+            "kernel_ms": ms, "vgprs": int(info.vgprs), "scratch_bytes": int(info.scratch_bytes),
+            "newton_iterations": solve.newton_iterations, "flags": solve.work.context.flags(),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved/8000.0}}
+
+
 def fused(n=1000000, steps=200, per_launch=10):
     """RK4 with `per_launch` steps fused into one launch (xrays_bench's SUB_STEPS = 10)."""
     from graph_framework_amd.xrays import Rk4ColdPlasmaEfit
@@ -86,6 +113,8 @@ if __name__ == "__main__":
         out = loss()
     elif what == "loss_per_ray":
         out = loss(per_ray=True)
+    elif what == "solver_f32":
+        out = solver_f32()
     elif what == "fused":
         out = fused()
     else:

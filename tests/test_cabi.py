@@ -97,3 +97,28 @@ def test_table_compaction_is_exact():
     for _group, child, factor, parent in derived:
         k = float.fromhex(factor)
         np.testing.assert_array_equal(k*tables[int(parent)], tables[int(child)])
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """No CPU fallback: without libgf_hip.so nothing in the package can compute."""
+    from graph_framework_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libgf_hip.so"))
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _lib.load()
+    from graph_framework_amd import generate_source
+    with pytest.raises(ImportError):
+        generate_source(os.path.join(WORKLOADS, "korc_initialize_gamma_f64.gfir"))
+
+
+def test_product_package_never_imports_the_oracle():
+    """oracle/ is test infrastructure: no module of graph_framework_amd may import it."""
+    import glob
+    package = os.path.join(ROOT, "graph_framework_amd")
+    for path in glob.glob(os.path.join(package, "*.py")):
+        with open(path) as f:
+            text = f.read()
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), path
+    for path in glob.glob(os.path.join(package, "csrc", "*")):
+        with open(path) as f:
+            assert "oracle/" not in f.read(), path
