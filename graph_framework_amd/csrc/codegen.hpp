@@ -387,7 +387,10 @@ inline lowered lower(const item &it, const codegen_options &opt = codegen_option
 // fp32 division as hipcc lowers it (denormals on): scale, r = rcp(d) + one Newton step,
 // q = n*r refined by two residual steps, a third residual folded in by div_fmas, un-scale,
 // fixup.  Shared per denominator like the fp64 form below; identical bits while no scaling is
-// needed (|d| in [2^-60, 2^60] is checked per pass; quotients below 2^-100 are not).
+// needed: hardware scales when 1/d, n/d or the residual would leave the normal range, i.e.
+// |d| outside [2^-126, 2^126], |n/d| outside the normal range, or 0 < |n| < 2^-102.  Checked per
+// pass: |d| in [2^-100, 2^100] and finite results; numerators below 2^-102 are not checked
+// (their quotients may differ in the last bit).
 __device__ __forceinline__ float gf_rcp(const float d) {
     const float r = __builtin_amdgcn_rcpf(d);
     const float e = __builtin_fmaf(-d, r, 1.0f);
@@ -750,8 +753,8 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
         s << "                real finite_check = " << literal(0.0) << ";\n";
         for (size_t k = 0; k < it.setters.size(); k++) s << "                finite_check += sv" << k << ";\n";
         for (size_t o = 0; o < it.outputs.size(); o++) s << "                finite_check += so" << o << ";\n";
-        s << "                bad = !__builtin_isfinite(finite_check) || !(dmin >= " << (f64 ? "0x1p-500" : "0x1p-60f")
-          << ") || !(dmax <= " << (f64 ? "0x1p+500" : "0x1p+60f") << ");\n";
+        s << "                bad = !__builtin_isfinite(finite_check) || !(dmin >= " << (f64 ? "0x1p-500" : "0x1p-100f")
+          << ") || !(dmax <= " << (f64 ? "0x1p+500" : "0x1p+100f") << ");\n";
         s << "            }\n";
         s << "            if (__builtin_expect(bad, 0)) atomicOr(flags, 1u);\n";
     } else {

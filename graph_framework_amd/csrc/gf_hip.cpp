@@ -536,9 +536,10 @@ static int check_flags(gfhip_context *ctx) {
     GFHIP_TRY(ctx, hipMemcpy(&flags, ctx->device_flags, sizeof(flags), hipMemcpyDeviceToHost), "hipMemcpy(flags)");
     if ((flags & 1u) && !ctx->flags_reported) {
         ctx->flags_reported = true;
-        std::fprintf(stderr, "graph_framework_amd: a denominator left [2^-500, 2^500] or a result is not finite; "
-                             "fp64 quotients are no longer guaranteed bit-identical to IEEE division. "
-                             "Rebuild with GFHIP_DIVISION=ieee for the exact sequence.\n");
+        std::fprintf(stderr, "graph_framework_amd: a denominator left the window in which the shared-reciprocal "
+                             "division is the IEEE sequence ([2^-500, 2^500] fp64, [2^-100, 2^100] fp32) or a "
+                             "result is not finite; quotients are no longer guaranteed bit-identical to IEEE "
+                             "division.  Rebuild with GFHIP_DIVISION=ieee for the exact sequence.\n");
     }
     return 0;
 }

@@ -108,7 +108,7 @@ int gfhip_converge_per_ray(gfhip_kernel *kernel, double tolerance, size_t max_it
 int gfhip_wait(gfhip_context *ctx);
 
 /* Status bits raised by kernels since the context was created (after a drain).
- * Bit 0: a lane's fp64 denominator left [2^-500, 2^500] (or a result was not finite), so
+ * Bit 0: a lane's denominator left [2^-500, 2^500] (fp64) / [2^-100, 2^100] (fp32), or a result was not finite, so
  * the shared-reciprocal division is no longer guaranteed bit-identical to IEEE division
  * for that lane; gfhip_wait() also reports this once on stderr. */
 int gfhip_get_flags(gfhip_context *ctx, unsigned int *flags);
