@@ -84,6 +84,7 @@ struct codegen_options {
     uint32_t park_window = 100;         ///< ... uses closer than this share one reload
     uint32_t park_max_slots = 32;       ///< LDS slots of block_size elements each
     uint32_t elements_per_lane = 0;     ///< rays per lane (0 = auto = 1; 2/4 = vector loads, GFHIP_ELEMENTS_PER_LANE)
+    int division_fixup = -1;            ///< v_div_fixup after each shared-reciprocal quotient: 1 yes, 0 no, -1 auto
     bool prefetch_next_tile = false;    ///< EXPERIMENT: load the next grid-stride tile's inputs before computing this one
     uint32_t sched_barrier_every = 0;   ///< EXPERIMENT: __builtin_amdgcn_sched_barrier(0) every N nodes (0 = none)
     uint32_t park_prefetch = 50;        ///< issue a reload this many nodes before its first use (< window)
@@ -96,6 +97,7 @@ struct codegen_options {
         if (const char *e = std::getenv("GFHIP_PARK_MIN_RANGE")) o.park_min_range = static_cast<uint32_t> (std::atoi(e));
         if (const char *e = std::getenv("GFHIP_PARK_WINDOW")) o.park_window = static_cast<uint32_t> (std::atoi(e));
         if (const char *e = std::getenv("GFHIP_ELEMENTS_PER_LANE")) o.elements_per_lane = static_cast<uint32_t> (std::atoi(e));
+        if (const char *e = std::getenv("GFHIP_DIV_FIXUP")) o.division_fixup = std::string(e) != "0" ? 1 : 0;
         if (const char *e = std::getenv("GFHIP_PREFETCH_NEXT")) o.prefetch_next_tile = std::string(e) == "1";
         if (const char *e = std::getenv("GFHIP_SCHED_BARRIER")) o.sched_barrier_every = static_cast<uint32_t> (std::atoi(e));
         if (const char *e = std::getenv("GFHIP_PARK_PREFETCH")) o.park_prefetch = static_cast<uint32_t> (std::atoi(e));
@@ -382,7 +384,22 @@ inline lowered lower(const item &it, const codegen_options &opt = codegen_option
     s << "#include <hip/hip_runtime.h>\n";
     s << "typedef " << real << " real;\n";
     const bool use_shared = opt.shared_reciprocal;
+//  v_div_fixup only acts on special operands.  Inside the checked window (finite non-zero
+//  denominator, finite results) dropping it changes exactly one thing: a quotient with
+//  numerator -0 and a positive denominator comes out +0 instead of -0.  A zero of either sign
+//  is the same value to every later operation except a division by it (non-finite, flagged)
+//  and atan2, so the fixup (680 of 7700 VALU instructions in the RK4 step, 8 % of its time)
+//  is kept only for items that contain an atan2 node.
+    bool fixup = opt.division_fixup == 1;
+    if (opt.division_fixup < 0) {
+        fixup = false;
+        for (auto &c : it.code) {
+            if (c.op == GFIR_ATAN2) fixup = true;
+        }
+    }
     if (!f64) {
+        s << (fixup ? "#define GF_FIXUP(q, d, n) __builtin_amdgcn_div_fixupf(q, d, n)\n"
+                    : "#define GF_FIXUP(q, d, n) (q)\n");
         s << R"(
 // fp32 division as hipcc lowers it (denormals on): scale, r = rcp(d) + one Newton step,
 // q = n*r refined by two residual steps, a third residual folded in by div_fmas, un-scale,
@@ -401,11 +418,13 @@ __device__ __forceinline__ float gf_div(const float n, const float d, const floa
     const float e0 = __builtin_fmaf(-d, q0, n);
     const float q1 = __builtin_fmaf(e0, r, q0);
     const float e1 = __builtin_fmaf(-d, q1, n);
-    return __builtin_amdgcn_div_fixupf(__builtin_fmaf(e1, r, q1), d, n);
+    return GF_FIXUP(__builtin_fmaf(e1, r, q1), d, n);
 }
 )";
     }
     if (f64) {
+        s << (fixup ? "#define GF_FIXUP(q, d, n) __builtin_amdgcn_div_fixup(q, d, n)\n"
+                    : "#define GF_FIXUP(q, d, n) (q)\n");
         s << R"(
 // IEEE fp64 division as hipcc lowers it is: scale, r = rcp(d) refined by two Newton steps,
 // q = n*r, e = fma(-d, q, n), q' = fma(e, r, q), un-scale, fix special values.  A work item
@@ -423,7 +442,7 @@ __device__ __forceinline__ double gf_rcp(const double d) {
 __device__ __forceinline__ double gf_div(const double n, const double d, const double r) {
     const double q = n*r;
     const double e = __builtin_fma(-d, q, n);
-    return __builtin_amdgcn_div_fixup(__builtin_fma(e, r, q), d, n);
+    return GF_FIXUP(__builtin_fma(e, r, q), d, n);
 }
 // pow(x, 1.5) = x*sqrt(x) with the rounding error of the square root carried into the
 // product (s + t ~ sqrt(x) to ~100 bits), i.e. rounded once from the exact value almost
