@@ -46,6 +46,33 @@ def available_cores():
     return cores
 
 
+def dag_flops(path):
+    """Floating-point operations of one pass of a work item, counted from its GFIR records:
+    add/sub/mul/div/sqrt/pow 1, fma 2, integer power p -> p-1 multiplies (SURVEY.md §8(d) counts
+    the same way: ~4.3 kflop per RK4 ray-step)."""
+    import struct
+    with open(path, "rb") as f:
+        data = f.read()
+    _magic, _dtype, ni, _no, _ns, nt, nins, nb, _r = struct.unpack_from("<8s8I", data, 0)
+    pos = 40 + nb
+    for _ in range(ni):
+        (n,) = struct.unpack_from("<I", data, pos)
+        pos += 4 + n
+    for _ in range(nt):
+        rows, cols = struct.unpack_from("<II", data, pos)
+        pos += 8 + 8*rows*cols
+    flops = 0
+    for i in range(nins):
+        op, _a, _b, _c, aux = struct.unpack_from("<5I", data, pos + 56*i)
+        if op in (2, 3, 4, 5, 7, 9):
+            flops += 1
+        elif op == 6:
+            flops += 2
+        elif op == 8:
+            flops += max(aux, 1) - 1
+    return flops
+
+
 def measured_traffic(kernel_name, rays):
     """HBM bytes per launch from the committed PMC passes (profiles/r01_traffic.json: rocprofv3
     --pmc FETCH_SIZE / WRITE_SIZE run on this same command), if they are for this launch size."""
@@ -179,6 +206,7 @@ def main():
     if rank == 0:
         info = solve.solver.kernel.info()
         value = total*args.steps/elapsed
+        flops = dag_flops(workload("solver_kernel"))
         achieved = n_local*BYTES_PER_RAY_STEP_F64/(kernel_ms*1.0e-3)/1.0e9 if kernel_ms > 0 else 0.0
         line = {
             "metric": "ray-steps/sec on xrays_bench cold-plasma; achieved HBM GB/s vs peak",
@@ -208,6 +236,9 @@ def main():
                          "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r01_solver_kernel.md)",
                          "note": "the kernel is FP64-VALU issue bound (7.8k vector instructions per ray-step, "
                                  "VALU busy 76 % at one wave per SIMD), not HBM bound: see DESIGN.md section 3"},
+            "fp64_vector": {"flops_per_ray_step": flops, "achieved_tflops": value/world*flops/1.0e12,
+                            "peak_tflops": 78.6, "frac": value/world*flops/1.0e12/78.6,
+                            "note": "per GPU; reference-DAG operation count, the roof that binds this kernel"},
             "value_with_sync_host": total*args.steps/(elapsed + sync_elapsed),
             "newton_iterations": solve.newton_iterations,
         }

@@ -193,15 +193,10 @@ inline lowered lower(const item &it, const codegen_options &opt = codegen_option
             }
             return false;
         };
+//  First pass: a table is derived from an EARLIER table (stored or itself derived; parents
+//  always have a smaller index, so there are no cycles).
         for (size_t j = 0; j < it.tables.size(); j++) {
-            for (size_t i = 0; i < it.tables.size(); i++) {
-                if (i == j) continue;
-//  Only parents that are stored (roots) or derive from an earlier-decided table: no cycles.
-                int root = static_cast<int> (i);
-                bool cycle = false;
-                while (parent[root] >= 0) { root = parent[root]; if (root == static_cast<int> (j)) { cycle = true; break; } }
-                if (cycle || (i > j && parent[i] < 0 && false)) continue;
-                if (i > j) continue;    // decided tables only
+            for (size_t i = 0; i < j; i++) {
                 double k;
                 if (derive(it.tables[i], it.tables[j], k)) {
                     parent[j] = static_cast<int> (i);
@@ -210,8 +205,9 @@ inline lowered lower(const item &it, const codegen_options &opt = codegen_option
                 }
             }
         }
-//  Second pass: an earlier root that is an exact multiple of a LATER root (e.g. 3*c, stored
-//  before c) is re-parented to it.
+//  Second pass: a still-stored table that is an exact multiple of a LATER stored table (e.g.
+//  3*c met before c) is re-parented to it; only stored tables become parents here, and they
+//  keep no parent of a smaller index, so chains stay acyclic.
         for (size_t j = 0; j < it.tables.size(); j++) {
             if (parent[j] >= 0) continue;
             for (size_t i = j + 1; i < it.tables.size(); i++) {
