@@ -64,6 +64,16 @@ def load():
     """Load libgf_hip.so and declare every entry point.  Raises if it is absent."""
     global _lib
     if _lib is None:
+        if not os.path.exists(LIB_PATH) and os.path.basename(LIB_PATH) == "libgf_hip.so":
+#  A tree that was checked out without its built artefacts: build the HIP library now if the
+#  toolchain is here (seconds).  This is the product's own build, not a fallback path.
+            hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+            if os.path.exists(hipcc) and os.path.isdir(os.path.join(HERE, "csrc")):
+                import subprocess
+                try:
+                    subprocess.check_call(["make", "-C", os.path.join(HERE, "csrc"), "-s", "HIPCC=" + hipcc])
+                except (OSError, subprocess.CalledProcessError):
+                    pass
         if not os.path.exists(LIB_PATH):
             raise ImportError("graph_framework_amd: %s is missing — run __graft_entry__.build() "
                               "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
