@@ -57,10 +57,12 @@ def cli_distribution(num_rays, seed=0, dtype="f64"):
 class Rk4ColdPlasmaEfit:
     """solver::rk4<dispersion::cold_plasma<T>> on an EFIT equilibrium."""
 
-    def __init__(self, state, dtype="f64", index=0, stream=None, prefix="", items=None):
+    def __init__(self, state, dtype="f64", index=0, stream=None, prefix="", items=None, device_state=False):
         """state: dict of host arrays (or scalars) t,w,x,y,z,kx,ky,kz for this shard.
         items: optional {workload name: GFIR bytes} (e.g. received by broadcast from rank 0);
-        by default the exported workload files are read."""
+        by default the exported workload files are read.
+        device_state: keep the state and the residual in torch CUDA tensors (self.device) adopted
+        by the context, so that torch (streams, collectives, output.TrajectoryWriter) can use them."""
         self.dtype = dtype
         self.items = items or {}
         self.np_dtype = _NP[dtype]
@@ -71,7 +73,23 @@ class Rk4ColdPlasmaEfit:
         self.prefix = prefix
         self.keys = [prefix + k for k in STATE]
         self.residual_key = prefix + "residual"
+        self.device = None
+        self.torch_stream = None
+        if device_state:
+            import torch
+            where = torch.device("cuda", index)
+            torch_dtype = torch.float64 if dtype == "f64" else torch.float32
+            if stream is None:
+#  A dedicated torch stream (the default stream's handle is 0, which the C ABI reads as
+#  "create a private stream"): kernels and torch work issued under it are ordered.
+                self.torch_stream = torch.cuda.Stream(device=where)
+                stream = self.torch_stream.cuda_stream
+            self.device = {k: torch.from_numpy(self.host[k]).to(where) for k in STATE}
+            self.device["residual"] = torch.zeros(self.num_rays, dtype=torch_dtype, device=where)
         self.work = Manager(index, stream)
+        if self.device is not None:
+            for k, tensor in self.device.items():
+                self.work.context.set_buffer(prefix + k, tensor)
         self.newton = None
         self.solver = None
         self.newton_iterations = None

@@ -122,3 +122,26 @@ def test_product_package_never_imports_the_oracle():
     for path in glob.glob(os.path.join(package, "csrc", "*")):
         with open(path) as f:
             assert "oracle/" not in f.read(), path
+
+
+def test_result_file_roundtrip(tmp_path):
+    """output.ResultFile writes (time, num_rays, 1) variables with an unlimited time dimension
+    (output.hpp:260-273, :354-400); read back with the fixture reader."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_fixtures import H5File
+    from graph_framework_amd.output import ResultFile
+    path = str(tmp_path / "result0.nc")
+    out = ResultFile(path, 5)
+    for name in ("time", "x"):
+        out.create_variable(name)
+    for record in range(3):
+        out.write({"time": np.full(5, 0.5*record), "x": np.arange(5.0) + record})
+    out.close()
+    f = H5File(path)
+    x = f.read("x")
+    time = f.read("time")
+    f.close()
+    assert x.shape == (3, 5, 1) and time.shape == (3, 5, 1)
+    np.testing.assert_array_equal(x[2, :, 0], np.arange(5.0) + 2)
+    np.testing.assert_array_equal(time[1, :, 0], np.full(5, 0.5))
