@@ -57,7 +57,8 @@ def cli_distribution(num_rays, seed=0, dtype="f64"):
 class Rk4ColdPlasmaEfit:
     """solver::rk4<dispersion::cold_plasma<T>> on an EFIT equilibrium."""
 
-    def __init__(self, state, dtype="f64", index=0, stream=None, prefix="", items=None, device_state=False):
+    def __init__(self, state, dtype="f64", index=0, stream=None, prefix="", items=None, device_state=False,
+                 dispersion="cold_plasma"):
         """state: dict of host arrays (or scalars) t,w,x,y,z,kx,ky,kz for this shard.
         items: optional {workload name: GFIR bytes} (e.g. received by broadcast from rank 0);
         by default the exported workload files are read.
@@ -65,6 +66,9 @@ class Rk4ColdPlasmaEfit:
         by the context, so that torch (streams, collectives, output.TrajectoryWriter) can use them."""
         self.dtype = dtype
         self.items = items or {}
+#  Exported (dispersion x rk4 x EFIT) combinations: cold_plasma (dt = 1e-3, xrays_bench) and
+#  ordinary_wave (dt = 1e-4, graph_tests/physics_test.cpp:583-618).
+        self.workload_prefix = "" if dispersion == "cold_plasma" else dispersion + "_"
         self.np_dtype = _NP[dtype]
         sizes = [np.size(state[k]) for k in STATE if np.ndim(state[k]) > 0]
         self.num_rays = max(sizes) if sizes else 1
@@ -96,7 +100,7 @@ class Rk4ColdPlasmaEfit:
         self.newton_last_max = None
 
     def _item(self, name):
-        return self.items[name] if name in self.items else workload(name, self.dtype)
+        return self.items[name] if name in self.items else workload(self.workload_prefix + name, self.dtype)
 
     def _initial(self):
         return {self.prefix + k: self.host[k] for k in STATE}

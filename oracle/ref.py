@@ -87,9 +87,10 @@ class Reference:
     def dispersion(self, state, dtype="f64"):
         return self._run(dtype, "dispersion", [state[k] for k in ("t", "w", "x", "y", "z", "kx", "ky", "kz")])
 
-    def trace(self, state, dt, num_steps, save_every=0, newton_var=1, dtype="f64"):
+    def trace(self, state, dt, num_steps, save_every=0, newton_var=1, dtype="f64", dispersion="cold_plasma"):
         """Returns records[(num_saved), 9, n] (t,w,x,y,z,kx,ky,kz,residual) and info."""
-        out, info = self._run(dtype, "trace", [state[k] for k in ("t", "w", "x", "y", "z", "kx", "ky", "kz")],
+        command = "trace" if dispersion == "cold_plasma" else "trace_ordinary"
+        out, info = self._run(dtype, command, [state[k] for k in ("t", "w", "x", "y", "z", "kx", "ky", "kz")],
                               repr(float(dt)), num_steps, save_every, newton_var)
         return out.reshape(-1, 9, out.shape[1]), info
 

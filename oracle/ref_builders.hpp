@@ -482,6 +482,33 @@ leaf<T> cold_plasma_D(leaf<T> w, vec3<T> k_vec, leaf<T> x, leaf<T> y, leaf<T> z,
 }
 
 // ---------------------------------------------------------------------------
+// dispersion::ordinary_wave::D, dispersion.hpp:785-812:  D = 1 - wpe^2/w^2 - nperp^2.
+// ---------------------------------------------------------------------------
+template<typename T>
+leaf<T> ordinary_wave_D(leaf<T> w, vec3<T> k_vec, leaf<T> x, leaf<T> y, leaf<T> z, efit<T> &eq,
+                        std::vector<leaf<T>> *debug = nullptr) {
+    (void)debug;
+    const T epsilon0 = 8.8541878138E-12;
+    const T mu0 = M_PI*4.0E-7;
+    const T q = 1.602176634E-19;
+    const T me = 9.1093837015E-31;
+    const T c = static_cast<T> (1.0)/std::sqrt(epsilon0*mu0);
+    auto ne = eq.get_electron_density(x, y, z);
+    auto wpe2 = ne*q*q/(epsilon0*me*c*c);
+    auto n = k_vec/w;
+    auto b_vec = eq.get_magnetic_field(x, y, z);
+    auto b_hat = b_vec->unit();
+    auto nperp = b_hat->cross(n);
+    auto nperp2 = nperp->dot(nperp);
+    auto w2 = w*w;
+    return 1.0 - wpe2/w2 - nperp2;
+}
+
+template<typename T>
+using dispersion_function = leaf<T> (*)(leaf<T>, vec3<T>, leaf<T>, leaf<T>, leaf<T>, efit<T> &,
+                                        std::vector<leaf<T>> *);
+
+// ---------------------------------------------------------------------------
 // dispersion::dispersion_interface ctor, dispersion.hpp:1369-1434.
 // ---------------------------------------------------------------------------
 template<typename T>
@@ -490,10 +517,13 @@ struct dispersion_interface {
     leaf<T> D, dxdt, dydt, dzdt, dkxdt, dkydt, dkzdt;
     leaf<T> dDdw, dDdkx, dDdky, dDdkz, dDdx, dDdy, dDdz;
 
+    dispersion_function<T> function;
+
     dispersion_interface(leaf<T> w, leaf<T> kx, leaf<T> ky, leaf<T> kz,
-                         leaf<T> x, leaf<T> y, leaf<T> z, efit<T> &eq) :
+                         leaf<T> x, leaf<T> y, leaf<T> z, efit<T> &eq,
+                         dispersion_function<T> f = cold_plasma_D<T>) :
     k_vec(kx*eq.esup(0) + ky*eq.esup(1) + kz*eq.esup(2)),
-    D(cold_plasma_D(w, k_vec, x, y, z, eq)) {
+    D(f(w, k_vec, x, y, z, eq, nullptr)), function(f) {
         auto dkdx = k_vec->df(x);
         auto dkdy = k_vec->df(y);
         auto dkdz = k_vec->df(z);
@@ -583,7 +613,7 @@ work_item<T> make_solver_kernel(const ray_variables<T> &v, efit<T> &eq, const T 
                                graph::pseudo_variable(v.kz + kz1/2.0),
                                graph::pseudo_variable(v.x + x1/2.0),
                                graph::pseudo_variable(v.y + y1/2.0),
-                               graph::pseudo_variable(v.z + z1/2.0), eq);
+                               graph::pseudo_variable(v.z + z1/2.0), eq, D.function);
     auto kx2 = dt*D2.dkxdt, ky2 = dt*D2.dkydt, kz2 = dt*D2.dkzdt;
     auto x2 = dt*D2.dxdt, y2 = dt*D2.dydt, z2 = dt*D2.dzdt;
 
@@ -593,7 +623,7 @@ work_item<T> make_solver_kernel(const ray_variables<T> &v, efit<T> &eq, const T 
                                graph::pseudo_variable(v.kz + kz2/2.0),
                                graph::pseudo_variable(v.x + x2/2.0),
                                graph::pseudo_variable(v.y + y2/2.0),
-                               graph::pseudo_variable(v.z + z2/2.0), eq);
+                               graph::pseudo_variable(v.z + z2/2.0), eq, D.function);
     auto kx3 = dt*D3.dkxdt, ky3 = dt*D3.dkydt, kz3 = dt*D3.dkzdt;
     auto x3 = dt*D3.dxdt, y3 = dt*D3.dydt, z3 = dt*D3.dzdt;
 
@@ -605,7 +635,7 @@ work_item<T> make_solver_kernel(const ray_variables<T> &v, efit<T> &eq, const T 
                                graph::pseudo_variable(v.kz + kz3),
                                graph::pseudo_variable(v.x + x3),
                                graph::pseudo_variable(v.y + y3),
-                               graph::pseudo_variable(v.z + z3), eq);
+                               graph::pseudo_variable(v.z + z3), eq, D.function);
     auto kx4 = dt*D4.dkxdt, ky4 = dt*D4.dkydt, kz4 = dt*D4.dkzdt;
     auto x4 = dt*D4.dxdt, y4 = dt*D4.dydt, z4 = dt*D4.dzdt;
 

@@ -116,12 +116,14 @@ static int cmd_dispersion(const raw_tables &raw, const char *in_path, const char
 //  First saved record = state after Newton (residual = D*D of the last Newton pass).
 template<typename T>
 static int cmd_trace(const raw_tables &raw, const char *in_path, const char *out_path,
-                     const double dt, const size_t num_steps, const size_t save_every, const int newton_var) {
+                     const double dt, const size_t num_steps, const size_t save_every, const int newton_var,
+                     const bool ordinary = false) {
     efit<T> eq(raw);
     size_t n;
     auto cols = convert<T> (read_columns(in_path, 8, n));
     ray_variables<T> v;
-    dispersion_interface<T> D(v.w, v.kx, v.ky, v.kz, v.x, v.y, v.z, eq);
+    dispersion_interface<T> D(v.w, v.kx, v.ky, v.kz, v.x, v.y, v.z, eq,
+                              ordinary ? ordinary_wave_D<T> : cold_plasma_D<T>);
     std::vector<T> residual(n, 0);
 
     if (newton_var >= 0) {
@@ -574,6 +576,18 @@ static int dispatch(const raw_tables &raw, int argc, char **argv) {
         return cmd_export<T> (raw, argv[4], atof(argv[5]), argv[6]);
     } else if (cmd == "dispersion" && argc == 6) {
         return cmd_dispersion<T> (raw, argv[4], argv[5]);
+    } else if (cmd == "trace_ordinary" && argc == 10) {
+        return cmd_trace<T> (raw, argv[4], argv[5], atof(argv[6]), strtoull(argv[7], nullptr, 10),
+                             strtoull(argv[8], nullptr, 10), atoi(argv[9]), true);
+    } else if (cmd == "export_ordinary" && argc == 7) {
+        efit<T> eq(raw);
+        ray_variables<T> v;
+        dispersion_interface<T> D(v.w, v.kx, v.ky, v.kz, v.x, v.y, v.z, eq, ordinary_wave_D<T>);
+        work_item<T> loss = make_loss_kernel(v, D.D, 1, static_cast<T> (1.0));
+        loss.write_gfir("loss_kernel", std::string(argv[4]) + "/ordinary_wave_loss_kernel_kx_" + argv[6] + ".gfir");
+        work_item<T> solver = make_solver_kernel(v, eq, static_cast<T> (atof(argv[5])), D);
+        solver.write_gfir("solver_kernel", std::string(argv[4]) + "/ordinary_wave_solver_kernel_" + argv[6] + ".gfir");
+        return 0;
     } else if (cmd == "trace" && argc == 10) {
         return cmd_trace<T> (raw, argv[4], argv[5], atof(argv[6]), strtoull(argv[7], nullptr, 10),
                              strtoull(argv[8], nullptr, 10), atoi(argv[9]));

@@ -60,6 +60,13 @@ def main():
     out["bench_newton_iterations"] = np.array(info["newton_iterations"])
     out["bench_newton_last_max"] = np.array(info["newton_last_max"])
 
+#  physics_test.cpp:583-618: ordinary_wave on EFIT, omega = 590, dt = 1e-4, 10000 RK4 steps.
+    subprocess.check_call([ref.BINARY, R.tables, "f64", "export_ordinary", workloads, "0.0001", "f64"])
+    records, info = R.trace(bench_state(1, w=590.0), 1.0e-4, 10000, 1000, 1, dispersion="ordinary_wave")
+    out["ordinary_steps"] = np.arange(0, 10001, 1000)
+    out["ordinary_records"] = records[:, :, 0]
+    out["ordinary_newton_iterations"] = np.array(info["newton_iterations"])
+
 #  Seeded rays inside the plasma.
     state = random_plasma_state(64, seed=2024)
     records, _ = R.trace(state, 1.0e-3, 20, 1, -1)

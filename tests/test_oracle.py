@@ -161,3 +161,21 @@ def test_compiled_oracle_equals_interpreter():
         outs_b, _ = compiled.run(b, steps=steps, threads=3)
         for x, y in zip(a + outs_a, b + outs_b):
             np.testing.assert_array_equal(x, y)
+
+
+def test_ordinary_wave_reflection_matches_reference(golden):
+    """graph_tests/physics_test.cpp:583-618 (test_efit): ordinary_wave, omega = 590, dt = 1e-4,
+    10000 RK4 steps; the ray must reflect.  Interpreter vs the reference graph layer, bit for bit."""
+    state = bench_state(1, w=590.0)
+    columns = [state[k] for k in STATE]
+    iterations, _, _ = item("ordinary_wave_loss_kernel_kx_f64").converge(columns)
+    assert iterations == int(golden["ordinary_newton_iterations"])
+    solver = item("ordinary_wave_solver_kernel_f64")
+    done = 0
+    for step, record in zip(golden["ordinary_steps"], golden["ordinary_records"]):
+        if step > done:
+            solver.run(columns, steps=int(step) - done)
+            done = int(step)
+        for k, expected in zip(STATE, record[:8]):
+            assert state[k][0] == expected, (step, k)
+    assert state["kx"][0] > 0.0 and golden["ordinary_records"][0][5] < 0.0      # reflected
