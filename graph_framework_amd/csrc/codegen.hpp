@@ -42,7 +42,9 @@
 #include <tuple>
 #include <vector>
 
+#include <fstream>
 #include "gfir_item.hpp"
+#include "schedule.hpp"
 
 namespace gfhip {
 
@@ -83,6 +85,7 @@ struct codegen_options {
     uint32_t park_min_range = 1500;     ///< park values whose live range exceeds this many nodes ...
     uint32_t park_window = 100;         ///< ... uses closer than this share one reload
     uint32_t park_max_slots = 32;       ///< LDS slots of block_size elements each
+    bool schedule_for_pressure = true;  ///< emit in the pressure-aware order of schedule.hpp (GFHIP_SCHEDULE=source: item order)
     uint32_t elements_per_lane = 0;     ///< rays per lane (0 = auto = 1; 2/4 = vector loads, GFHIP_ELEMENTS_PER_LANE)
     int division_fixup = -1;            ///< v_div_fixup after each shared-reciprocal quotient: 1 yes, 0 no, -1 auto
     bool prefetch_next_tile = false;    ///< EXPERIMENT: load the next grid-stride tile's inputs before computing this one
@@ -96,6 +99,7 @@ struct codegen_options {
         if (const char *e = std::getenv("GFHIP_PARK")) o.park_in_lds = std::string(e) != "0";
         if (const char *e = std::getenv("GFHIP_PARK_MIN_RANGE")) o.park_min_range = static_cast<uint32_t> (std::atoi(e));
         if (const char *e = std::getenv("GFHIP_PARK_WINDOW")) o.park_window = static_cast<uint32_t> (std::atoi(e));
+        if (const char *e = std::getenv("GFHIP_SCHEDULE")) o.schedule_for_pressure = std::string(e) != "source";
         if (const char *e = std::getenv("GFHIP_ELEMENTS_PER_LANE")) o.elements_per_lane = static_cast<uint32_t> (std::atoi(e));
         if (const char *e = std::getenv("GFHIP_DIV_FIXUP")) o.division_fixup = std::string(e) != "0" ? 1 : 0;
         if (const char *e = std::getenv("GFHIP_PREFETCH_NEXT")) o.prefetch_next_tile = std::string(e) == "1";
@@ -128,7 +132,17 @@ inline const char *compile_flags() {
 //------------------------------------------------------------------------------
 ///  @brief Lower one item.
 //------------------------------------------------------------------------------
-inline lowered lower(const item &it, const codegen_options &opt = codegen_options::from_environment()) {
+inline lowered lower(const item &original, const codegen_options &opt = codegen_options::from_environment()) {
+    item scheduled;
+    if (const char *path = std::getenv("GFHIP_ORDER_FILE")) {   // EXPERIMENT: an explicit emission order
+        std::ifstream f(path);
+        std::vector<uint32_t> order;
+        for (uint32_t v; f >> v;) order.push_back(v);
+        if (order.size() == original.code.size()) scheduled = reorder(original, order);
+    } else if (opt.schedule_for_pressure) {
+        scheduled = schedule_for_pressure(original);
+    }
+    const item &it = scheduled.code.empty() ? original : scheduled;
     lowered out;
     const bool f64 = it.dtype == GFIR_F64;
     const char *real = f64 ? "double" : "float";
@@ -377,7 +391,9 @@ inline lowered lower(const item &it, const codegen_options &opt = codegen_option
     out.kernel_name = "gfhip_" + it.name;
     s << "// Generated by graph_framework_amd (GFIR -> gfx950).  Work item \"" << it.name << "\": "
       << it.code.size() << " nodes, " << it.tables.size() << " tables in " << out.packs.size() << " packs.\n";
-    s << "#include <hip/hip_runtime.h>\n";
+//  hipRTC predefines the runtime declarations; its include search does not always reach the
+//  ROCm headers (a stand-alone process on a box whose /opt/rocm hipRTC has no header path).
+    s << "#if !defined(__HIPCC_RTC__)\n#include <hip/hip_runtime.h>\n#endif\n";
     s << "typedef " << real << " real;\n";
     const bool use_shared = opt.shared_reciprocal;
 //  v_div_fixup only acts on special operands.  Inside the checked window (finite non-zero
@@ -393,6 +409,19 @@ inline lowered lower(const item &it, const codegen_options &opt = codegen_option
             if (c.op == GFIR_ATAN2) fixup = true;
         }
     }
+//  Window check of the denominators: |d| is tracked through an fp32 image that is monotonic in
+//  |d| — |d| itself for float, the high dword of a double read as a float (sign, 11 exponent
+//  bits, 20 mantissa bits) — so that one v_maximum3_f32 / v_minimum3_f32 (gfx950, abs modifiers
+//  free) folds TWO denominators into the running extreme: 1 VALU instruction per denominator
+//  instead of 3 with fp64 fmax/fmin.  Both are the IEEE-754-2019 NaN-propagating forms: a
+//  high dword that reads as a float NaN (|d| >= 2^1017, infinity, NaN) poisons the accumulator
+//  and fails the final comparison, like any other value outside the window.
+    s << R"(
+__device__ __forceinline__ float gf_magnitude(const float d) { return __builtin_fabsf(d); }
+__device__ __forceinline__ float gf_magnitude(const double d) {
+    return __builtin_fabsf(__builtin_bit_cast(float, static_cast<unsigned int> (__builtin_bit_cast(unsigned long long, d) >> 32)));
+}
+)";
     if (!f64) {
         s << (fixup ? "#define GF_FIXUP(q, d, n) __builtin_amdgcn_div_fixupf(q, d, n)\n"
                     : "#define GF_FIXUP(q, d, n) (q)\n");
@@ -657,8 +686,8 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
                         if (!reciprocal_done[c.b]) {
                             reciprocal_done[c.b] = true;
                             s << ind << "const real q" << c.b << " = gf_rcp(" << N(c.b) << ");\n";
-                            s << ind << "dmax = __builtin_fmax" << sfx << "(dmax, __builtin_fabs" << sfx << "(" << N(c.b) << "));\n";
-                            s << ind << "dmin = __builtin_fmin" << sfx << "(dmin, __builtin_fabs" << sfx << "(" << N(c.b) << "));\n";
+                            s << ind << "dmax = __builtin_elementwise_maximum(dmax, gf_magnitude(" << N(c.b) << "));\n";
+                            s << ind << "dmin = __builtin_elementwise_minimum(dmin, gf_magnitude(" << N(c.b) << "));\n";
                         }
                         s << ind << "const real r" << i << " = gf_div(" << N(c.a) << ", " << N(c.b) << ", q" << c.b << ");\n";
                     } else {
@@ -762,14 +791,14 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
 //  results are then not guaranteed bit-identical and the item should be rebuilt with
 //  GFHIP_DIVISION=ieee.  Never observed on the hot-path workloads (|d| spans 1e-30..1e+30).
         s << "            bool bad = false;\n";
-        s << "            real dmax = " << literal(1.0) << ", dmin = " << literal(1.0) << ";   // extreme |denominator| of this pass\n";
+        s << "            float dmax = gf_magnitude(" << literal(1.0) << "), dmin = dmax;   // extreme |denominator| of this pass\n";
         s << "            {\n";
         emit_body(true);
         s << "                real finite_check = " << literal(0.0) << ";\n";
         for (size_t k = 0; k < it.setters.size(); k++) s << "                finite_check += sv" << k << ";\n";
         for (size_t o = 0; o < it.outputs.size(); o++) s << "                finite_check += so" << o << ";\n";
-        s << "                bad = !__builtin_isfinite(finite_check) || !(dmin >= " << (f64 ? "0x1p-500" : "0x1p-100f")
-          << ") || !(dmax <= " << (f64 ? "0x1p+500" : "0x1p+100f") << ");\n";
+        s << "                bad = !__builtin_isfinite(finite_check) || !(dmin >= gf_magnitude(" << (f64 ? "0x1p-500" : "0x1p-100f")
+          << ")) || !(dmax <= gf_magnitude(" << (f64 ? "0x1p+500" : "0x1p+100f") << "));\n";
         s << "            }\n";
 //  Set the status bit once: lanes that find it set only read it (an atomic per flagged lane on
 //  one address serialises at ~11 ns each — 0.7 ms for 1e7 flagged lanes).
