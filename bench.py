@@ -234,8 +234,8 @@ def main():
                          "kernel": info.name.decode(), "kernel_ms": kernel_ms, "launches": int(launches),
                          "algorithmic_bytes_per_launch": n_local*BYTES_PER_RAY_STEP_F64,
                          "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r01_solver_kernel.md)",
-                         "note": "the kernel is FP64-VALU issue bound (7.8k vector instructions per ray-step, "
-                                 "VALU busy 76 % at one wave per SIMD), not HBM bound: see DESIGN.md section 3"},
+                         "note": "the kernel is FP64-VALU issue bound (6.4k vector instructions per ray-step, "
+                                 "VALU busy 86 % at one wave per SIMD), not HBM bound: see DESIGN.md section 3"},
             "fp64_vector": {"flops_per_ray_step": flops, "achieved_tflops": value/world*flops/1.0e12,
                             "peak_tflops": 78.6, "frac": value/world*flops/1.0e12/78.6,
                             "note": "per GPU; reference-DAG operation count, the roof that binds this kernel"},
