@@ -54,11 +54,13 @@ def cli_distribution(num_rays, seed=0, dtype="f64"):
     return {k: np.ascontiguousarray(v, dtype=np_dtype) for k, v in state.items()}
 
 
-class Rk4ColdPlasmaEfit:
-    """solver::rk4<dispersion::cold_plasma<T>> on an EFIT equilibrium."""
+class RaySolver:
+    """solver::solver_interface (solver.hpp:123-430) over exported work items: any
+    (integrator x dispersion relation x equilibrium) whose `loss_kernel_<unknown>` and
+    `solver_kernel` items exist as `<workload_prefix><item>_<dtype>.gfir`."""
 
     def __init__(self, state, dtype="f64", index=0, stream=None, prefix="", items=None, device_state=False,
-                 dispersion="cold_plasma"):
+                 dispersion="cold_plasma", workload_prefix=None):
         """state: dict of host arrays (or scalars) t,w,x,y,z,kx,ky,kz for this shard.
         items: optional {workload name: GFIR bytes} (e.g. received by broadcast from rank 0);
         by default the exported workload files are read.
@@ -68,7 +70,10 @@ class Rk4ColdPlasmaEfit:
         self.items = items or {}
 #  Exported (dispersion x rk4 x EFIT) combinations: cold_plasma (dt = 1e-3, xrays_bench) and
 #  ordinary_wave (dt = 1e-4, graph_tests/physics_test.cpp:583-618).
-        self.workload_prefix = "" if dispersion == "cold_plasma" else dispersion + "_"
+        if workload_prefix is not None:
+            self.workload_prefix = workload_prefix
+        else:
+            self.workload_prefix = "" if dispersion == "cold_plasma" else dispersion + "_"
         self.np_dtype = _NP[dtype]
         sizes = [np.size(state[k]) for k in STATE if np.ndim(state[k]) > 0]
         self.num_rays = max(sizes) if sizes else 1
@@ -155,3 +160,8 @@ class Rk4ColdPlasmaEfit:
     def residual(self):
         out = np.empty(self.num_rays, dtype=self.np_dtype)
         return self.work.copy_to_host(self.residual_key, out)
+
+
+class Rk4ColdPlasmaEfit(RaySolver):
+    """solver::rk4<dispersion::cold_plasma<T>> on an EFIT equilibrium (the xrays_bench
+    combination; `dispersion="ordinary_wave"` selects physics_test.cpp:583-618's)."""

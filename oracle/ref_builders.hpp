@@ -301,11 +301,34 @@ struct raw_tables {
 };
 
 // ---------------------------------------------------------------------------
+// equilibrium::generic (equilibrium.hpp:236-470): what the dispersion relations ask of
+// an equilibrium.  One ion species everywhere on the path (deuterium mass 3.34449469e-27,
+// charge 1: equilibrium.hpp:489,618,742,871,998,1475).
+// ---------------------------------------------------------------------------
+template<typename T>
+struct equilibrium_base {
+    virtual ~equilibrium_base() {}
+    virtual leaf<T> get_electron_density(leaf<T> x, leaf<T> y, leaf<T> z) = 0;
+    virtual leaf<T> get_ion_density(leaf<T> x, leaf<T> y, leaf<T> z) = 0;
+    virtual leaf<T> get_electron_temperature(leaf<T> x, leaf<T> y, leaf<T> z) = 0;
+    virtual leaf<T> get_ion_temperature(leaf<T> x, leaf<T> y, leaf<T> z) = 0;
+    virtual vec3<T> get_magnetic_field(leaf<T> x, leaf<T> y, leaf<T> z) = 0;
+
+//  generic::get_esup1..3, equilibrium.hpp:379-420.
+    vec3<T> esup(const int i) {
+        auto one = graph::one<T> ();
+        auto zero = graph::zero<T> ();
+        return i == 0 ? graph::vector(one, zero, zero)
+             : (i == 1 ? graph::vector(zero, one, zero) : graph::vector(zero, zero, one));
+    }
+};
+
+// ---------------------------------------------------------------------------
 // Restatement of equilibrium::efit (equilibrium.hpp:1146-1616) against the
 // reference node API.  Member-init bug of :1478 and ni = te of :1361 kept.
 // ---------------------------------------------------------------------------
 template<typename T>
-class efit {
+class efit : public equilibrium_base<T> {
 public:
     T psimin, dpsi, rmin, dr, zmin, dz;
     backend::buffer<T> te_c[4], ne_c[4], pres_c[4], fpol_c[4], c[4][4];
@@ -398,18 +421,11 @@ public:
         }
     }
 
-    leaf<T> get_electron_density(leaf<T> x, leaf<T> y, leaf<T> z) { set_cache(x, y, z); return ne_cache; }
-    leaf<T> get_ion_density(leaf<T> x, leaf<T> y, leaf<T> z) { set_cache(x, y, z); return ni_cache; }
-    leaf<T> get_electron_temperature(leaf<T> x, leaf<T> y, leaf<T> z) { set_cache(x, y, z); return te_cache; }
-    vec3<T> get_magnetic_field(leaf<T> x, leaf<T> y, leaf<T> z) { set_cache(x, y, z); return b_cache; }
-
-//  generic::get_esup1..3, equilibrium.hpp:379-420.
-    vec3<T> esup(const int i) {
-        auto one = graph::one<T> ();
-        auto zero = graph::zero<T> ();
-        return i == 0 ? graph::vector(one, zero, zero)
-             : (i == 1 ? graph::vector(zero, one, zero) : graph::vector(zero, zero, one));
-    }
+    leaf<T> get_electron_density(leaf<T> x, leaf<T> y, leaf<T> z) override { set_cache(x, y, z); return ne_cache; }
+    leaf<T> get_ion_density(leaf<T> x, leaf<T> y, leaf<T> z) override { set_cache(x, y, z); return ni_cache; }
+    leaf<T> get_electron_temperature(leaf<T> x, leaf<T> y, leaf<T> z) override { set_cache(x, y, z); return te_cache; }
+    leaf<T> get_ion_temperature(leaf<T> x, leaf<T> y, leaf<T> z) override { set_cache(x, y, z); return ti_cache; }
+    vec3<T> get_magnetic_field(leaf<T> x, leaf<T> y, leaf<T> z) override { set_cache(x, y, z); return b_cache; }
 };
 
 // ---------------------------------------------------------------------------
@@ -417,7 +433,7 @@ public:
 // helpers :326-332, :348-353; ion species equilibrium.hpp:1475).
 // ---------------------------------------------------------------------------
 template<typename T>
-leaf<T> cold_plasma_D(leaf<T> w, vec3<T> k_vec, leaf<T> x, leaf<T> y, leaf<T> z, efit<T> &eq,
+leaf<T> cold_plasma_D(leaf<T> w, vec3<T> k_vec, leaf<T> x, leaf<T> y, leaf<T> z, equilibrium_base<T> &eq,
                       std::vector<leaf<T>> *debug = nullptr) {
     const T epsilon0 = 8.8541878138E-12;
     const T mu0 = M_PI*4.0E-7;
@@ -485,7 +501,7 @@ leaf<T> cold_plasma_D(leaf<T> w, vec3<T> k_vec, leaf<T> x, leaf<T> y, leaf<T> z,
 // dispersion::ordinary_wave::D, dispersion.hpp:785-812:  D = 1 - wpe^2/w^2 - nperp^2.
 // ---------------------------------------------------------------------------
 template<typename T>
-leaf<T> ordinary_wave_D(leaf<T> w, vec3<T> k_vec, leaf<T> x, leaf<T> y, leaf<T> z, efit<T> &eq,
+leaf<T> ordinary_wave_D(leaf<T> w, vec3<T> k_vec, leaf<T> x, leaf<T> y, leaf<T> z, equilibrium_base<T> &eq,
                         std::vector<leaf<T>> *debug = nullptr) {
     (void)debug;
     const T epsilon0 = 8.8541878138E-12;
@@ -505,7 +521,7 @@ leaf<T> ordinary_wave_D(leaf<T> w, vec3<T> k_vec, leaf<T> x, leaf<T> y, leaf<T> 
 }
 
 template<typename T>
-using dispersion_function = leaf<T> (*)(leaf<T>, vec3<T>, leaf<T>, leaf<T>, leaf<T>, efit<T> &,
+using dispersion_function = leaf<T> (*)(leaf<T>, vec3<T>, leaf<T>, leaf<T>, leaf<T>, equilibrium_base<T> &,
                                         std::vector<leaf<T>> *);
 
 // ---------------------------------------------------------------------------
@@ -520,7 +536,7 @@ struct dispersion_interface {
     dispersion_function<T> function;
 
     dispersion_interface(leaf<T> w, leaf<T> kx, leaf<T> ky, leaf<T> kz,
-                         leaf<T> x, leaf<T> y, leaf<T> z, efit<T> &eq,
+                         leaf<T> x, leaf<T> y, leaf<T> z, equilibrium_base<T> &eq,
                          dispersion_function<T> f = cold_plasma_D<T>) :
     k_vec(kx*eq.esup(0) + ky*eq.esup(1) + kz*eq.esup(2)),
     D(f(w, k_vec, x, y, z, eq, nullptr)), function(f) {
@@ -566,7 +582,8 @@ struct ray_variables {
 //  solver::newton (newton.hpp:34-51): setter x - step*func/func->df(x), output func*func.
 template<typename T>
 work_item<T> make_loss_kernel(const ray_variables<T> &v, leaf<T> func, const int var, const T step) {
-    leaf<T> target = var == 0 ? v.w : (var == 1 ? v.kx : (var == 2 ? v.ky : v.kz));
+    const leaf<T> unknowns[7] = {v.w, v.kx, v.ky, v.kz, v.x, v.y, v.z};     // var: 0 w, 1 kx, 2 ky, 3 kz, 4 x, 5 y, 6 z
+    leaf<T> target = unknowns[var];
     return work_item<T> (v.inputs(), {func*func}, {{target - step*func/func->df(target), target}});
 }
 
@@ -601,7 +618,7 @@ size_t converge(const work_item<T> &item, const size_t n, std::vector<T *> colum
 // solver_interface::compile, solver.hpp:303-349.
 // ---------------------------------------------------------------------------
 template<typename T>
-work_item<T> make_solver_kernel(const ray_variables<T> &v, efit<T> &eq, const T dt_value,
+work_item<T> make_solver_kernel(const ray_variables<T> &v, equilibrium_base<T> &eq, const T dt_value,
                                 dispersion_interface<T> &D) {
     auto dt = graph::constant<T> (dt_value);
     auto kx1 = dt*D.dkxdt, ky1 = dt*D.dkydt, kz1 = dt*D.dkzdt;

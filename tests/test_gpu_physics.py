@@ -1,0 +1,99 @@
+"""graph_tests/solver_test.cpp and graph_tests/physics_test.cpp on the HIP backend.
+
+Every scenario of tests/physics_scenarios.py is driven through the product's solver mirror
+(graph_framework_amd.xrays.RaySolver -> workflow.Manager -> C ABI -> generated gfx950 kernels)
+and compared with the record the reference's own graph layer produced
+(tests/golden/physics_golden.json): bit for bit where the graph is +,-,*,/,fma only, 1e-12
+where it contains exp (ocml vs glibc); the reference test's own assertion must hold as well.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, STATE
+
+import physics_scenarios
+
+pytestmark = pytest.mark.gpu
+
+
+class GpuSolver:
+    """The scenarios' solver interface over xrays.RaySolver (one context, device-resident state;
+    host edits are pushed with sync_device before the next device operation, as the reference
+    tests do with solve.sync_device())."""
+
+    def __init__(self, name, num_rays=1):
+        from graph_framework_amd.xrays import RaySolver
+        self.solve = RaySolver({k: np.zeros(num_rays) for k in STATE}, workload_prefix="physics_%s_" % name)
+        self.num_rays = num_rays
+        self.newton_iterations = []
+        self.started = False            # device buffers exist
+        self.dirty = False              # host edited since the last upload
+        self.stale = False              # device advanced since the last download
+        self.residual_key = None
+
+    def _push(self):
+        if self.started and self.dirty:
+            self.solve.sync_device()
+        self.dirty = False
+
+    def _pull(self):
+        if self.started and self.stale:
+            self.solve.sync_host()
+        self.stale = False
+
+    def set(self, key, value, index=None):
+        self._pull()
+        if index is None:
+            self.solve.host[key][:] = value
+        else:
+            self.solve.host[key][index] = value
+        self.dirty = True
+
+    def get(self, key, index=0):
+        self._pull()
+        return float(self.solve.host[key][index])
+
+    def init(self, variable, tolerance=1.0e-30):
+        self._push()
+        self.solve.init(variable, tolerance)
+        self.started = True
+        self.dirty = False
+        self.stale = True
+        self.newton_iterations.append(self.solve.newton_iterations)
+        self.residual_key = self.solve.prefix + "newton_residual"
+
+    def compile(self):
+        self._push()
+        self.solve.compile()
+        self.started = True
+        self.dirty = False
+
+    def step(self):
+        self._push()
+        self.solve.step()
+        self.stale = True
+        self.residual_key = self.solve.residual_key
+
+    def state(self):
+        self._pull()
+        residual = np.empty(self.num_rays)
+        self.solve.work.copy_to_host(self.residual_key, residual)
+        assert self.solve.work.context.flags() == 0
+        return [[float(self.solve.host[k][i]) for k in STATE] + [float(residual[i])] for i in range(self.num_rays)]
+
+
+@pytest.fixture(scope="module")
+def physics_golden():
+    with open(os.path.join(GOLDEN, "physics_golden.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("name,scenario", physics_scenarios.all_scenarios(),
+                         ids=[name for name, _ in physics_scenarios.all_scenarios()])
+def test_reference_test_scenarios_on_the_gpu(physics_golden, name, scenario):
+    result = scenario(GpuSolver)
+    physics_scenarios.compare(result, physics_golden[name], exact=not physics_scenarios.uses_exp(name))
+    assert result["holds"]

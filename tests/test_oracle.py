@@ -179,3 +179,65 @@ def test_ordinary_wave_reflection_matches_reference(golden):
         for k, expected in zip(STATE, record[:8]):
             assert state[k][0] == expected, (step, k)
     assert state["kx"][0] > 0.0 and golden["ordinary_records"][0][5] < 0.0      # reflected
+
+
+# ---------------------------------------------------------------------------
+# graph_tests/solver_test.cpp and graph_tests/physics_test.cpp: the scenarios of
+# tests/physics_scenarios.py replayed on the interpreter, bit for bit against what
+# oracle/_ref/gf_ref_physics produced on the reference graph layer.
+# ---------------------------------------------------------------------------
+import json                                                     # noqa: E402
+
+import physics_scenarios                                        # noqa: E402
+
+
+class OracleSolver:
+    """solver_interface over oracle/gfir_interp.c: host columns, one Item per kernel."""
+
+    def __init__(self, name, num_rays=1):
+        self.prefix = "physics_" + name
+        self.columns = [np.zeros(num_rays) for _ in STATE]
+        self.residual = np.zeros(num_rays)
+        self.newton_iterations = []
+        self.solver = None
+
+    def set(self, key, value, index=None):
+        if index is None:
+            self.columns[STATE.index(key)][:] = value
+        else:
+            self.columns[STATE.index(key)][index] = value
+
+    def get(self, key, index=0):
+        return float(self.columns[STATE.index(key)][index])
+
+    def init(self, variable, tolerance=1.0e-30):
+        iterations, _, outs = item("%s_loss_kernel_%s_f64" % (self.prefix, variable)).converge(self.columns, tolerance)
+        self.residual = outs[-1]
+        self.newton_iterations.append(iterations)
+
+    def compile(self):
+        self.solver = item(self.prefix + "_solver_kernel_f64")
+
+    def step(self):
+        outs, _ = self.solver.run(self.columns)
+        self.residual = outs[0]
+
+    def state(self):
+        return [[float(c[i]) for c in self.columns] + [float(self.residual[i])] for i in range(self.residual.size)]
+
+
+@pytest.fixture(scope="module")
+def physics_golden():
+    with open(os.path.join(GOLDEN, "physics_golden.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("name,scenario", physics_scenarios.all_scenarios(),
+                         ids=[name for name, _ in physics_scenarios.all_scenarios()])
+def test_reference_test_scenarios_match_reference_bit_for_bit(physics_golden, name, scenario):
+    """Every integrator (rk2, rk4, split_simplextic), dispersion relation (simple, gaussian_well,
+    bohm_gross, light_wave, acoustic_wave, ordinary_wave, extra_ordinary_wave, cold_plasma) and
+    analytic equilibrium the reference tests use; the reference's assertion must hold too."""
+    result = scenario(OracleSolver)
+    physics_scenarios.compare(result, physics_golden[name], exact=True)
+    assert result["holds"]
