@@ -145,3 +145,20 @@ def test_result_file_roundtrip(tmp_path):
     assert x.shape == (3, 5, 1) and time.shape == (3, 5, 1)
     np.testing.assert_array_equal(x[2, :, 0], np.arange(5.0) + 2)
     np.testing.assert_array_equal(time[1, :, 0], np.full(5, 0.5))
+
+
+def test_random_items_lower_to_valid_gfx950_code(lib, tmp_path):
+    """The fuzz generator's items (tests/gfir_random.py) parse, lower deterministically and
+    cross-compile for gfx950 without a GPU (the GPU run is tests/test_gpu_fuzz.py)."""
+    import subprocess
+    import gfir_random
+    from graph_framework_amd import generate_source
+    from graph_framework_amd.build import HIPCC, KERNEL_FLAGS
+    blob, records = gfir_random.random_item(5, "f64", num_nodes=600)
+    source, source_hash = generate_source(blob)
+    assert generate_source(blob) == (source, source_hash)
+    # every record is emitted exactly once whatever the emission order
+    assert len(set(re.findall(r"const real (r\d+) =", source))) >= records
+    path = tmp_path / "fuzz.hip"
+    path.write_text(source)
+    subprocess.check_call([HIPCC, "--genco"] + KERNEL_FLAGS + ["-o", str(tmp_path / "fuzz.hsaco"), str(path)])
