@@ -109,6 +109,44 @@ def stream(dtype, n=10000000, steps=50):
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved/8000.0}}
 
 
+def stream7(dtype, n=10000000, steps=50):
+    """Calibration with the xkorc push's own traffic pattern: 7 arrays read and written in place
+    by a trivial item (v <- v*1.0000001 + 0.5), built here as GFIR."""
+    import struct
+    import graph_framework_amd as gfa
+    np_dtype = np.float32 if dtype == "f32" else np.float64
+    code = []
+    for i in range(7):
+        code.append((1, i, 0xFFFFFFFF, 0xFFFFFFFF, 0, (0.0,)*4))                 # INPUT i
+    code.append((0, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0, (float(np_dtype(1.0000001)), 0.0, 0.0, 0.0)))
+    code.append((0, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0, (0.5, 0.0, 0.0, 0.0)))
+    for i in range(7):
+        code.append((6, i, 7, 8, 0, (0.0,)*4))                                   # FMA(v, a, b)
+    name = b"stream7\0"
+    blob = struct.pack("<8s8I", b"GFIR0001", 1 if dtype == "f64" else 0, 7, 0, 7, 0, len(code), len(name), 0) + name
+    for i in range(7):
+        blob += struct.pack("<I", 4) + ("v%d" % i).encode() + b"\0\0"
+    for op, a, b, c, aux, imm in code:
+        blob += struct.pack("<6I4d", op, a, b, c, aux, 0, *imm)
+    for i in range(7):
+        blob += struct.pack("<II", 9 + i, i)
+    ctx = gfa.Context(0)
+    kernel = ctx.add_kernel(blob, n)
+    ctx.compile()
+    kernel.create_kernel_call(["v%d" % i for i in range(7)], [], [np.full(n, 0.25, np_dtype) for _ in range(7)])
+    for _ in range(5):
+        kernel.run(1)
+    ctx.enable_timing(True)
+    ctx.wait()
+    for _ in range(steps):
+        kernel.run(1)
+    ms, launches = kernel.timing()
+    achieved = n*np_dtype().itemsize*14/(ms*1.0e-3)/1.0e9
+    return {"workload": "stream calibration (7 arrays in/out, the push's pattern), %d elements %s" % (n, dtype),
+            "kernel_ms": ms, "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                                          "frac": achieved/8000.0}}
+
+
 def fused(n=1000000, steps=200, per_launch=10):
     """RK4 with `per_launch` steps fused into one launch (xrays_bench's SUB_STEPS = 10)."""
     from graph_framework_amd.xrays import Rk4ColdPlasmaEfit
@@ -134,6 +172,8 @@ if __name__ == "__main__":
         out = loss()
     elif what == "loss_per_ray":
         out = loss(per_ray=True)
+    elif what.startswith("stream7"):
+        out = stream7(what.split("_")[1])
     elif what.startswith("stream"):
         out = stream(what.split("_")[1])
     elif what == "solver_f32":

@@ -87,8 +87,11 @@ struct codegen_options {
     uint32_t park_max_slots = 32;       ///< LDS slots of block_size elements each
     bool schedule_for_pressure = true;  ///< emit in the pressure-aware order of schedule.hpp (GFHIP_SCHEDULE=source: item order)
     uint32_t elements_per_lane = 0;     ///< rays per lane (0 = auto = 1; 2/4 = vector loads, GFHIP_ELEMENTS_PER_LANE)
+    int packed_pairs = -1;              ///< fp32 items: two rays per lane as a float2, arithmetic on v_pk_*_f32
+                                        ///< (-1 = auto, GFHIP_PACKED=0/1)
     int division_fixup = -1;            ///< v_div_fixup after each shared-reciprocal quotient: 1 yes, 0 no, -1 auto
     bool prefetch_next_tile = false;    ///< EXPERIMENT: load the next grid-stride tile's inputs before computing this one
+    uint32_t prefetch_min_gap = 600;    ///< ... after the latest gather followed by this many gather-free nodes
     uint32_t sched_barrier_every = 0;   ///< EXPERIMENT: __builtin_amdgcn_sched_barrier(0) every N nodes (0 = none)
     uint32_t park_prefetch = 50;        ///< issue a reload this many nodes before its first use (< window)
 
@@ -101,8 +104,10 @@ struct codegen_options {
         if (const char *e = std::getenv("GFHIP_PARK_WINDOW")) o.park_window = static_cast<uint32_t> (std::atoi(e));
         if (const char *e = std::getenv("GFHIP_SCHEDULE")) o.schedule_for_pressure = std::string(e) != "source";
         if (const char *e = std::getenv("GFHIP_ELEMENTS_PER_LANE")) o.elements_per_lane = static_cast<uint32_t> (std::atoi(e));
+        if (const char *e = std::getenv("GFHIP_PACKED")) o.packed_pairs = std::atoi(e);
         if (const char *e = std::getenv("GFHIP_DIV_FIXUP")) o.division_fixup = std::string(e) != "0" ? 1 : 0;
         if (const char *e = std::getenv("GFHIP_PREFETCH_NEXT")) o.prefetch_next_tile = std::string(e) == "1";
+        if (const char *e = std::getenv("GFHIP_PREFETCH_MIN_GAP")) o.prefetch_min_gap = static_cast<uint32_t> (std::atoi(e));
         if (const char *e = std::getenv("GFHIP_SCHED_BARRIER")) o.sched_barrier_every = static_cast<uint32_t> (std::atoi(e));
         if (const char *e = std::getenv("GFHIP_PARK_PREFETCH")) o.park_prefetch = static_cast<uint32_t> (std::atoi(e));
         if (const char *e = std::getenv("GFHIP_PARK_MAX_SLOTS")) o.park_max_slots = static_cast<uint32_t> (std::atoi(e));
@@ -137,8 +142,14 @@ inline lowered lower(const item &original, const codegen_options &opt = codegen_
     if (const char *path = std::getenv("GFHIP_ORDER_FILE")) {   // EXPERIMENT: an explicit emission order
         std::ifstream f(path);
         std::vector<uint32_t> order;
-        for (uint32_t v; f >> v;) order.push_back(v);
-        if (order.size() == original.code.size()) scheduled = reorder(original, order);
+        std::vector<uint32_t> fences;                           // 4294967295 in the file = a fence before the next record
+        for (uint32_t v; f >> v;) {
+            if (v == GFIR_NONE) fences.push_back(static_cast<uint32_t> (order.size())); else order.push_back(v);
+        }
+        if (order.size() == original.code.size()) {
+            scheduled = reorder(original, order);
+            scheduled.fences = fences;
+        }
     } else if (opt.schedule_for_pressure) {
         scheduled = schedule_for_pressure(original);
     }
@@ -292,6 +303,11 @@ inline lowered lower(const item &original, const codegen_options &opt = codegen_
         elements = 1;
     }
     if (elements != 1 && elements != 2 && elements != 4) elements = 1;
+//  Packed pairs (fp32 only): a lane owns two consecutive rays held as ONE float2, so that the
+//  arithmetic of the pass issues as v_pk_add/mul/fma_f32 — two rays per VALU slot instead of
+//  one (CDNA's fp32 vector peak is a packed-math figure).  Same IEEE operations per component.
+    const bool packed = it.dtype == GFIR_F32 && opt.packed_pairs == 1;
+    if (packed) elements = 2;
     out.elements = elements;
 
 //  LDS parking.  Measured on MI355X (1e6 rays, ms per RK4 step): none 0.359 (340 B/lane of
@@ -489,7 +505,36 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
 //  rays are identical (the benchmark) and is offered as gfhip_converge_per_ray.
     const bool has_converge = !it.setters.empty() && !it.outputs.empty() && elements == 1 &&
                               it.code.size() <= 1500;
+    if (packed) {
+        s << R"(
+typedef float real2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ real2 gf_fma2(const real2 a, const real2 b, const real2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ real2 gf_rcp(const real2 d) {
+    const real2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    const real2 e = gf_fma2(-d, r, (real2)(1.0f));
+    return gf_fma2(e, r, r);
+}
+__device__ __forceinline__ real2 gf_div(const real2 n, const real2 d, const real2 r) {
+    const real2 q0 = n*r;
+    const real2 e0 = gf_fma2(-d, q0, n);
+    const real2 q1 = gf_fma2(e0, r, q0);
+    const real2 e1 = gf_fma2(-d, q1, n);
+    const real2 q2 = gf_fma2(e1, r, q1);
+    return real2{GF_FIXUP(q2.x, d.x, n.x), GF_FIXUP(q2.y, d.y, n.y)};
+}
+#define GF_PAIR1(name, fn) __device__ __forceinline__ real2 name(const real2 a) { return real2{fn(a.x), fn(a.y)}; }
+#define GF_PAIR2(name, fn) __device__ __forceinline__ real2 name(const real2 a, const real2 b) { return real2{fn(a.x, b.x), fn(a.y, b.y)}; }
+GF_PAIR1(gf_sqrt2, __builtin_sqrtf)
+GF_PAIR1(gf_sin2, sinf)
+GF_PAIR1(gf_cos2, cosf)
+GF_PAIR1(gf_exp2, expf)
+GF_PAIR1(gf_log2, logf)
+GF_PAIR2(gf_pow2, powf)
+GF_PAIR2(gf_atan22, atan2f)
+)";
+    }
     out.has_converge = has_converge;
+    const std::string VT = packed ? "real2" : "real";         // type of a value of the pass
     auto emit_kernel = [&] (const bool converge) {
     s << "extern \"C\" __global__ void __launch_bounds__(" << out.block_size;
     if (opt.waves_per_simd) s << ", " << opt.waves_per_simd;
@@ -571,22 +616,27 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
         }
         s << "        real v" << i << "[" << E << "];  // " << symbol << "\n";
         if (E > 1) {
-            s << "        if (full) {\n"
-              << "            const vec_t t = *reinterpret_cast<const vec_t *> (in" << i << " + i);\n"
-              << "            for (unsigned int e = 0; e < " << E << "u; e++) v" << i << "[e] = t[e];\n"
-              << "        } else {\n"
-              << "            for (unsigned int e = 0; e < " << E << "u; e++) v" << i << "[e] = i + e < n ? in" << i << "[i + e] : " << literal(0.0) << ";\n"
-              << "        }\n";
+//  (loaded below, all arrays under one branch)
         } else if (prefetch) {
             s << "        v" << i << "[0] = next" << i << ";\n";
         } else {
             s << "        v" << i << "[0] = in" << i << "[i];\n";
         }
     }
-    if (prefetch) {
+    if (E > 1) {
+        s << "        if (full) {\n";
         for (size_t i = 0; i < it.symbols.size(); i++) {
-            s << "        if (g + stride < groups) next" << i << " = in" << i << "[g + stride];\n";
+            s << "            const vec_t t" << i << " = *reinterpret_cast<const vec_t *> (in" << i << " + i);\n";
         }
+        for (size_t i = 0; i < it.symbols.size(); i++) {
+            s << "            for (unsigned int e = 0; e < " << E << "u; e++) v" << i << "[e] = t" << i << "[e];\n";
+        }
+        s << "        } else {\n";
+        for (size_t i = 0; i < it.symbols.size(); i++) {
+            s << "            for (unsigned int e = 0; e < " << E << "u; e++) v" << i << "[e] = i + e < n ? in" << i << "[i + e] : "
+              << (packed ? "in" + std::to_string(i) + "[i]" : literal(0.0)) << ";\n";
+        }
+        s << "        }\n";
     }
     for (size_t o = 0; o < it.outputs.size(); o++) {
         s << "        real o" << o << "[" << E << "] = {};\n";
@@ -598,6 +648,15 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
           << "        for (;;) {\n"
           << "            if (active) {\n"
           << "            const unsigned int e = 0;\n";
+    } else if (packed) {
+        for (size_t i = 0; i < it.symbols.size(); i++) {
+            s << "        real2 V" << i << " = {v" << i << "[0], v" << i << "[1]};\n";
+        }
+        for (size_t o = 0; o < it.outputs.size(); o++) {
+            s << "        real2 O" << o << " = {};\n";
+        }
+        s << "        for (unsigned int step = 0; step < steps; step++) {\n";
+        s << "            {\n";
     } else {
         s << "        for (unsigned int step = 0; step < steps; step++) {\n";
         if (E > 1) {
@@ -609,10 +668,10 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
         }
     }
     for (size_t k = 0; k < it.setters.size(); k++) {
-        s << "            real sv" << k << ";\n";
+        s << "            " << VT << " sv" << k << ";\n";
     }
     for (size_t o = 0; o < it.outputs.size(); o++) {
-        s << "            real so" << o << ";\n";
+        s << "            " << VT << " so" << o << ";\n";
     }
 
 //  The node-for-node body.  `shared` = divisions through a reciprocal shared by all
@@ -631,6 +690,20 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
         auto index_expression = [&] (const uint32_t arg, const double scale, const double offset,
                                      const uint32_t length) -> std::string {
             std::ostringstream e;
+            if (packed) {
+//  Clamped quotient as a float2; the caller converts each component.
+                const std::string zero = "(real2)(" + literal(0.0) + ")";
+                const std::string top = "(real2)(" + literal(static_cast<double> (length - 1)) + ")";
+                e << "__builtin_elementwise_min(__builtin_elementwise_max(";
+                if (shared) {
+                    e << "gf_div(" << name_of(arg) << " - (real2)(" << literal(offset) << "), (real2)(" << literal(scale)
+                      << "), (real2)(" << literal(static_cast<double> (1.0f/static_cast<float> (scale))) << "))";
+                } else {
+                    e << "(" << name_of(arg) << " - (real2)(" << literal(offset) << "))/(real2)(" << literal(scale) << ")";
+                }
+                e << ", " << zero << "), " << top << ")";
+                return e.str();
+            }
             e << "static_cast<unsigned int> (__builtin_fmin" << sfx << "(__builtin_fmax" << sfx << "(";
             if (shared) {
 //  The reciprocal literal is the correctly rounded 1/scale; gf_div's residual step makes
@@ -659,75 +732,153 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
             }
         };
         auto N = [&] (const uint32_t v) -> const std::string & { return name[v]; };
+//  Value of table `t` at the cell of index group `group`: a load for stored tables, an exact
+//  multiple of the parent's value otherwise; one definition per (group, table).
+        std::function<std::string(const std::string &, uint32_t)> value_at =
+            [&] (const std::string &group, const uint32_t t) -> std::string {
+            const std::string value_name = "c" + group.substr(1) + "_" + std::to_string(t);
+            if (coefficients.insert(value_name).second) {
+                if (parent[t] >= 0) {
+                    const std::string from = value_at(group, static_cast<uint32_t> (parent[t]));
+                    s << ind << "const " << VT << " " << value_name << " = " << literal(factor[t]) << "*" << from << ";\n";
+                } else {
+                    const uint32_t pi = table_pack[t];
+                    const std::string base = (out.packs[pi].in_lds ? "lds" : "pack") + std::to_string(pi);
+                    if (packed) {
+                        s << ind << "const real2 " << value_name << " = {" << base << "[" << group << "_0 + " << table_column[t]
+                          << "u], " << base << "[" << group << "_1 + " << table_column[t] << "u]};\n";
+                    } else {
+                        s << ind << "const real " << value_name << " = " << base << "[" << group << " + " << table_column[t] << "u];\n";
+                    }
+                }
+            }
+            return value_name;
+        };
+        std::map<uint32_t, std::pair<std::string, uint32_t>> deferred;     // gather node -> (group, table)
+        auto define = [&] (const uint32_t v) {
+            auto found = deferred.find(v);
+            if (found == deferred.end()) return;
+            const std::string value = value_at(found->second.first, found->second.second);
+            s << ind << "const " << VT << " r" << v << " = " << value << ";\n";
+            deferred.erase(found);
+        };
+//  Next-tile prefetch: vmcnt retires in order, so a load issued before a gather makes the
+//  gather's wait last as long as the (HBM-latency) prefetch.  The prefetch goes after the last
+//  gather of the pass; the rest of the pass (>= ~20 % of it in the RK4 item) covers its latency.
+        size_t prefetch_position = 0;
+        {
+//  The latest gather that is followed by at least `prefetch_min_gap` gather-free nodes (the
+//  tail of the pass counts as a gap); failing that, the one followed by the widest gap.
+            std::vector<size_t> gathers;
+            for (size_t i = 0; i < it.code.size(); i++) {
+                if (it.code[i].op == GFIR_GATHER1 || it.code[i].op == GFIR_GATHER2) gathers.push_back(i);
+            }
+            size_t widest = 0;
+            bool satisfied = false;
+            for (size_t k = 0; k < gathers.size(); k++) {
+                const size_t next = k + 1 < gathers.size() ? gathers[k + 1] : it.code.size();
+                const size_t gap = next - gathers[k] - 1;
+                if (gap >= opt.prefetch_min_gap) {
+                    prefetch_position = gathers[k] + 1;
+                    satisfied = true;
+                } else if (!satisfied && gap > widest) {
+                    widest = gap;
+                    prefetch_position = gathers[k] + 1;
+                }
+            }
+        }
         for (size_t i = 0; i < it.code.size(); i++) {
             const gfir_instruction &c = it.code[i];
+            if (prefetch && i == prefetch_position) {
+//  Unconditional (a branch would split the scheduling region): passes before the last one of a
+//  fused launch, and the last tile, re-read this tile's own (cached) element.
+                s << ind << "unsigned long long ahead = (step + 1u == steps && g + stride < groups) ? g + stride : g;\n";
+                if (prefetch_position > 0) {
+//  Tie the address to the last gather's result, or the compiler hoists the loads to the top.
+                    s << ind << "asm volatile(\"\" : \"+v\"(ahead) : \"v\"(" << N(static_cast<uint32_t> (prefetch_position - 1)) << "));\n";
+                }
+                for (size_t k = 0; k < it.symbols.size(); k++) {
+                    s << ind << "next" << k << " = in" << k << "[ahead];\n";
+                }
+//  ... and keep the scheduler from sinking them to the end of the pass.
+                s << ind << "__builtin_amdgcn_sched_barrier(0);\n";
+            }
             reload(i);
-            if (opt.sched_barrier_every && i && i%opt.sched_barrier_every == 0) {
+            {
+                const uint32_t operands[3] = {c.a, c.b, c.c};
+                for (int k = 0; k < operand_count(c.op); k++) define(operands[k]);
+            }
+            if ((opt.sched_barrier_every && i && i%opt.sched_barrier_every == 0) ||
+                std::find(it.fences.begin(), it.fences.end(), static_cast<uint32_t> (i)) != it.fences.end()) {
                 s << ind << "__builtin_amdgcn_sched_barrier(0);\n";
             }
             switch (c.op) {
                 case GFIR_CONST:
-                    s << ind << "const real r" << i << " = " << literal(c.imm[0]) << ";\n";
+                    s << ind << "const " << VT << " r" << i << " = " << literal(c.imm[0]) << ";\n";
                     break;
                 case GFIR_INPUT:
-                    s << ind << "const real r" << i << " = v" << c.a << "[e];\n";
+                    s << ind << "const " << VT << " r" << i << " = " << (packed ? "V" + std::to_string(c.a) : "v" + std::to_string(c.a) + "[e]") << ";\n";
                     break;
                 case GFIR_ADD:
-                    s << ind << "const real r" << i << " = " << N(c.a) << " + " << N(c.b) << ";\n";
+                    s << ind << "const " << VT << " r" << i << " = " << N(c.a) << " + " << N(c.b) << ";\n";
                     break;
                 case GFIR_SUB:
-                    s << ind << "const real r" << i << " = " << N(c.a) << " - " << N(c.b) << ";\n";
+                    s << ind << "const " << VT << " r" << i << " = " << N(c.a) << " - " << N(c.b) << ";\n";
                     break;
                 case GFIR_MUL:
-                    s << ind << "const real r" << i << " = " << N(c.a) << "*" << N(c.b) << ";\n";
+                    s << ind << "const " << VT << " r" << i << " = " << N(c.a) << "*" << N(c.b) << ";\n";
                     break;
                 case GFIR_DIV:
                     if (shared) {
                         if (!reciprocal_done[c.b]) {
                             reciprocal_done[c.b] = true;
-                            s << ind << "const real q" << c.b << " = gf_rcp(" << N(c.b) << ");\n";
-                            s << ind << "dmax = __builtin_elementwise_maximum(dmax, gf_magnitude(" << N(c.b) << "));\n";
-                            s << ind << "dmin = __builtin_elementwise_minimum(dmin, gf_magnitude(" << N(c.b) << "));\n";
+                            s << ind << "const " << VT << " q" << c.b << " = gf_rcp(" << N(c.b) << ");\n";
+                            for (const char *member : {".x", ".y"}) {
+                                const std::string component = N(c.b) + (packed ? member : "");
+                                s << ind << "dmax = __builtin_elementwise_maximum(dmax, gf_magnitude(" << component << "));\n";
+                                s << ind << "dmin = __builtin_elementwise_minimum(dmin, gf_magnitude(" << component << "));\n";
+                                if (!packed) break;
+                            }
                         }
-                        s << ind << "const real r" << i << " = gf_div(" << N(c.a) << ", " << N(c.b) << ", q" << c.b << ");\n";
+                        s << ind << "const " << VT << " r" << i << " = gf_div(" << N(c.a) << ", " << N(c.b) << ", q" << c.b << ");\n";
                     } else {
-                        s << ind << "const real r" << i << " = " << N(c.a) << "/" << N(c.b) << ";\n";
+                        s << ind << "const " << VT << " r" << i << " = " << N(c.a) << "/" << N(c.b) << ";\n";
                     }
                     break;
                 case GFIR_FMA:
-                    s << ind << "const real r" << i << " = __builtin_fma" << sfx << "(" << N(c.a) << ", " << N(c.b)
+                    s << ind << "const " << VT << " r" << i << " = " << (packed ? std::string("gf_fma2") : "__builtin_fma" + std::string(sfx)) << "(" << N(c.a) << ", " << N(c.b)
                       << ", " << N(c.c) << ");\n";
                     break;
                 case GFIR_SQRT:
-                    s << ind << "const real r" << i << " = __builtin_sqrt" << sfx << "(" << N(c.a) << ");\n";
+                    s << ind << "const " << VT << " r" << i << " = " << (packed ? std::string("gf_sqrt2") : "__builtin_sqrt" + std::string(sfx)) << "(" << N(c.a) << ");\n";
                     break;
                 case GFIR_POWI: {
-                    s << ind << "const real r" << i << " = " << N(c.a);
+                    s << ind << "const " << VT << " r" << i << " = " << N(c.a);
                     for (uint32_t k = 1; k < c.aux; k++) s << "*" << N(c.a);
                     s << ";\n";
                     break;
                 }
                 case GFIR_POW:
                     if (f64 && opt.pow_three_halves && it.code[c.b].op == GFIR_CONST && it.code[c.b].imm[0] == 1.5) {
-                        s << ind << "const real r" << i << " = gf_pow_three_halves(r" << c.a << ");\n";
+                        s << ind << "const " << VT << " r" << i << " = gf_pow_three_halves(r" << c.a << ");\n";
                     } else {
-                        s << ind << "const real r" << i << " = pow" << sfx << "(" << N(c.a) << ", " << N(c.b) << ");\n";
+                        s << ind << "const " << VT << " r" << i << " = " << (packed ? std::string("gf_pow2") : "pow" + std::string(sfx)) << "(" << N(c.a) << ", " << N(c.b) << ");\n";
                     }
                     break;
                 case GFIR_SIN:
-                    s << ind << "const real r" << i << " = sin" << sfx << "(" << N(c.a) << ");\n";
+                    s << ind << "const " << VT << " r" << i << " = " << (packed ? std::string("gf_sin2") : "sin" + std::string(sfx)) << "(" << N(c.a) << ");\n";
                     break;
                 case GFIR_COS:
-                    s << ind << "const real r" << i << " = cos" << sfx << "(" << N(c.a) << ");\n";
+                    s << ind << "const " << VT << " r" << i << " = " << (packed ? std::string("gf_cos2") : "cos" + std::string(sfx)) << "(" << N(c.a) << ");\n";
                     break;
                 case GFIR_ATAN2:
-                    s << ind << "const real r" << i << " = atan2" << sfx << "(" << N(c.b) << ", " << N(c.a) << ");\n";
+                    s << ind << "const " << VT << " r" << i << " = " << (packed ? std::string("gf_atan22") : "atan2" + std::string(sfx)) << "(" << N(c.b) << ", " << N(c.a) << ");\n";
                     break;
                 case GFIR_EXP:
-                    s << ind << "const real r" << i << " = exp" << sfx << "(" << N(c.a) << ");\n";
+                    s << ind << "const " << VT << " r" << i << " = " << (packed ? std::string("gf_exp2") : "exp" + std::string(sfx)) << "(" << N(c.a) << ");\n";
                     break;
                 case GFIR_LOG:
-                    s << ind << "const real r" << i << " = log" << sfx << "(" << N(c.a) << ");\n";
+                    s << ind << "const " << VT << " r" << i << " = " << (packed ? std::string("gf_log2") : "log" + std::string(sfx)) << "(" << N(c.a) << ");\n";
                     break;
                 case GFIR_GATHER1:
                 case GFIR_GATHER2: {
@@ -739,6 +890,22 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
                     if (g == groups.end()) {
                         const std::string name = "g" + std::to_string(group_count++);
                         const pack &p = out.packs[table_pack[c.aux]];
+                        if (packed) {
+                            s << ind << "const real2 " << name << "_x = " << index_expression(c.a, c.imm[0], c.imm[1], two ? t.rows : t.cols) << ";\n";
+                            if (two) {
+                                s << ind << "const real2 " << name << "_y = " << index_expression(c.b, c.imm[2], c.imm[3], t.cols) << ";\n";
+                            }
+                            for (int component = 0; component < 2; component++) {
+                                const char *member = component ? ".y" : ".x";
+                                s << ind << "const unsigned int " << name << "_" << component << " = (static_cast<unsigned int> ("
+                                  << name << "_x" << member << ")";
+                                if (two) {
+                                    s << "*" << t.cols << "u + static_cast<unsigned int> (" << name << "_y" << member << ")";
+                                }
+                                s << ")*" << p.stride << "u;\n";
+                            }
+                            g = groups.insert({key, name}).first;
+                        } else {
                         s << ind << "const unsigned int " << name << " = (";
                         if (two) {
                             s << index_expression(c.a, c.imm[0], c.imm[1], t.rows) << "*" << t.cols << "u + "
@@ -748,25 +915,19 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
                         }
                         s << ")*" << p.stride << "u;\n";
                         g = groups.insert({key, name}).first;
-                    }
-//  Value of table `t` at this group's cell: a load for stored tables, an exact multiple of
-//  the parent's value otherwise; one definition per (group, table).
-                    std::function<std::string(uint32_t)> value_at = [&] (const uint32_t t) -> std::string {
-                        const std::string name = "c" + g->second.substr(1) + "_" + std::to_string(t);
-                        if (coefficients.insert(name).second) {
-                            if (parent[t] >= 0) {
-                                const std::string from = value_at(static_cast<uint32_t> (parent[t]));
-                                s << ind << "const real " << name << " = " << literal(factor[t]) << "*" << from << ";\n";
-                            } else {
-                                const uint32_t pi = table_pack[t];
-                                s << ind << "const real " << name << " = " << (out.packs[pi].in_lds ? "lds" : "pack") << pi
-                                  << "[" << g->second << " + " << table_column[t] << "u];\n";
-                            }
                         }
-                        return name;
-                    };
-                    const std::string value = value_at(c.aux);
-                    s << ind << "const real r" << i << " = " << value << ";\n";
+                    }
+//  A derived table's value (k*parent) is defined at its first use, not here: next to the
+//  parent's load it would make the pass wait for that load at once.  The load stays here.
+                    if (parent[c.aux] >= 0 && !plan[i].parked) {
+                        uint32_t root = c.aux;
+                        while (parent[root] >= 0) root = static_cast<uint32_t> (parent[root]);
+                        (void)value_at(g->second, root);
+                        deferred[static_cast<uint32_t> (i)] = {g->second, c.aux};
+                        break;
+                    }
+                    const std::string value = value_at(g->second, c.aux);
+                    s << ind << "const " << VT << " r" << i << " = " << value << ";\n";
                     break;
                 }
                 default:
@@ -777,6 +938,8 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
             }
         }
         reload(node_count);
+        for (auto &st : it.setters) define(st.value);
+        for (auto o : it.outputs) define(o);
         for (size_t k = 0; k < it.setters.size(); k++) {
             s << ind << "sv" << k << " = " << N(it.setters[k].value) << ";\n";
         }
@@ -794,10 +957,10 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
         s << "            float dmax = gf_magnitude(" << literal(1.0) << "), dmin = dmax;   // extreme |denominator| of this pass\n";
         s << "            {\n";
         emit_body(true);
-        s << "                real finite_check = " << literal(0.0) << ";\n";
+        s << "                " << VT << " finite_check = " << literal(0.0) << ";\n";
         for (size_t k = 0; k < it.setters.size(); k++) s << "                finite_check += sv" << k << ";\n";
         for (size_t o = 0; o < it.outputs.size(); o++) s << "                finite_check += so" << o << ";\n";
-        s << "                bad = !__builtin_isfinite(finite_check) || !(dmin >= gf_magnitude(" << (f64 ? "0x1p-500" : "0x1p-100f")
+        s << "                bad = !__builtin_isfinite(" << (packed ? "finite_check.x + finite_check.y" : "finite_check") << ") || !(dmin >= gf_magnitude(" << (f64 ? "0x1p-500" : "0x1p-100f")
           << ")) || !(dmax <= gf_magnitude(" << (f64 ? "0x1p+500" : "0x1p+100f") << "));\n";
         s << "            }\n";
 //  Set the status bit once: lanes that find it set only read it (an atomic per flagged lane on
@@ -811,10 +974,11 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
         s << "            }\n";
     }
     for (size_t o = 0; o < it.outputs.size(); o++) {
-        s << "            o" << o << "[e] = so" << o << ";\n";
+        s << "            " << (packed ? "O" + std::to_string(o) : "o" + std::to_string(o) + "[e]") << " = so" << o << ";\n";
     }
     for (size_t k = 0; k < it.setters.size(); k++) {
-        s << "            v" << it.setters[k].input << "[e] = sv" << k << ";\n";
+        const std::string input = std::to_string(it.setters[k].input);
+        s << "            " << (packed ? "V" + input : "v" + input + "[e]") << " = sv" << k << ";\n";
     }
     if (converge) {
 //  converge_item::run for this ray:  while (A && B && C && iterations++ < max) {...}
@@ -833,28 +997,41 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
     } else {
         s << "            }\n";
         s << "        }\n";
+        if (packed) {
+            for (size_t i = 0; i < it.symbols.size(); i++) {
+                if (out.input_written[i]) s << "        v" << i << "[0] = V" << i << ".x; v" << i << "[1] = V" << i << ".y;\n";
+            }
+            for (size_t o = 0; o < it.outputs.size(); o++) {
+                s << "        o" << o << "[0] = O" << o << ".x; o" << o << "[1] = O" << o << ".y;\n";
+            }
+        }
     }
 //  Stores: setters first, then outputs (cpu_context.hpp:522-580).
-    auto store = [&] (const std::string &pointer, const std::string &values) {
-        if (E > 1) {
-            s << "        if (full) {\n"
-              << "            vec_t t;\n"
-              << "            for (unsigned int e = 0; e < " << E << "u; e++) t[e] = " << values << "[e];\n"
-              << "            *reinterpret_cast<vec_t *> (" << pointer << " + i) = t;\n"
-              << "        } else {\n"
-              << "            for (unsigned int e = 0; e < " << E << "u; e++) if (i + e < n) " << pointer << "[i + e] = " << values << "[e];\n"
-              << "        }\n";
-        } else {
-            s << "        " << pointer << "[i] = " << values << "[0];\n";
-        }
-    };
+    std::vector<std::pair<std::string, std::string>> stores;               // (pointer, values)
     for (size_t i = 0; i < it.symbols.size(); i++) {
-        if (out.input_written[i]) {
-            store("in" + std::to_string(i), "v" + std::to_string(i));
-        }
+        if (out.input_written[i]) stores.push_back({"in" + std::to_string(i), "v" + std::to_string(i)});
     }
     for (size_t o = 0; o < it.outputs.size(); o++) {
-        store("out" + std::to_string(o), "o" + std::to_string(o));
+        stores.push_back({"out" + std::to_string(o), "o" + std::to_string(o)});
+    }
+    if (E > 1) {
+        s << "        if (full) {\n";
+        for (auto &st : stores) {
+            s << "            {\n"
+              << "                vec_t t;\n"
+              << "                for (unsigned int e = 0; e < " << E << "u; e++) t[e] = " << st.second << "[e];\n"
+              << "                *reinterpret_cast<vec_t *> (" << st.first << " + i) = t;\n"
+              << "            }\n";
+        }
+        s << "        } else {\n";
+        for (auto &st : stores) {
+            s << "            for (unsigned int e = 0; e < " << E << "u; e++) if (i + e < n) " << st.first << "[i + e] = " << st.second << "[e];\n";
+        }
+        s << "        }\n";
+    } else {
+        for (auto &st : stores) {
+            s << "        " << st.first << "[i] = " << st.second << "[0];\n";
+        }
     }
     s << "    }\n}\n";
     };

@@ -27,6 +27,8 @@ struct item {
     std::vector<gfir_instruction> code;
     std::vector<uint32_t> outputs;
     std::vector<gfir_setter> setters;
+    std::vector<uint32_t> fences;           ///< lowering hint (schedule.hpp): no instruction may be moved across the
+                                            ///< start of these records by the compiler's scheduler
 
     size_t element_size() const {
         return dtype == GFIR_F32 ? 4 : 8;

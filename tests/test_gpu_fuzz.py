@@ -52,3 +52,31 @@ def test_random_work_item_bit_exact(seed, dtype, inputs, nodes, outputs, setters
             got = context.copy_to_host(key, np.empty(rays, dtype=oracle_item.np_dtype))
             assert np.array_equal(got, want), (key, launch_steps, np.flatnonzero(got != want)[:5])
     context.close()
+
+
+def test_packed_pairs_mode_is_bit_exact(monkeypatch):
+    """GFHIP_PACKED=1 (fp32 items: two rays per lane as one float2, v_pk_*_f32 arithmetic; an
+    option, not the default — it is not faster on MI355X) computes the same bits,
+    including an odd ensemble whose last lane owns a single ray."""
+    from graph_framework_amd import Context
+    monkeypatch.setenv("GFHIP_PACKED", "1")
+    for seed, rays in ((21, 1001), (22, 2)):
+        blob, _ = gfir_random.random_item(seed, "f32", 6, 500, 3, 4)
+        oracle_item = gfir.Item(blob)
+        rng = np.random.default_rng(seed)
+        initial = [rng.uniform(-1.0, 1.0, rays).astype(np.float32) for _ in range(6)]
+        context = Context(0)
+        kernel = context.add_kernel(blob, rays)
+        context.compile()
+        in_keys, out_keys = ["in%d" % i for i in range(6)], ["out%d" % i for i in range(3)]
+        kernel.create_kernel_call(in_keys, out_keys, initial)
+        expected = [c.copy() for c in initial]
+        for launch_steps in (1, 2):
+            expected_out, _ = oracle_item.run(expected, steps=launch_steps)
+            kernel.run(launch_steps)
+            context.wait()
+            assert context.flags() == 0
+            for key, want in zip(in_keys + out_keys, expected + expected_out):
+                got = context.copy_to_host(key, np.empty(rays, dtype=np.float32))
+                assert np.array_equal(got, want), (key, launch_steps)
+        context.close()
