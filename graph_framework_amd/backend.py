@@ -118,8 +118,9 @@ class Context:
         self._keepalive.append(tensor)
         self._check(self.lib.gfhip_set_buffer(self.handle, key_of(key), tensor.data_ptr(), tensor.numel(), dtype))
 
-    def enable_timing(self, enable=True):
-        self._check(self.lib.gfhip_enable_timing(self.handle, 1 if enable else 0))
+    def enable_timing(self, enable=True, every=1):
+        """HIP events around every `every`-th launch of each kernel (see Kernel.timing)."""
+        self._check(self.lib.gfhip_enable_timing(self.handle, int(every) if enable else 0))
 
 
 class Kernel:

@@ -86,7 +86,7 @@ struct gfhip_context {
     unsigned long long *host_scalar = nullptr;     // pinned
     unsigned int *device_flags = nullptr;          // bit 0: a lane left the fast-division window
     bool flags_reported = false;
-    bool timing = false;
+    unsigned int timing = 0;                       // 0 = off, N = events around every Nth launch of a kernel
 
     int fail(const std::string &message) {
         error = message;
@@ -116,6 +116,7 @@ struct gfhip_kernel {
     int vgprs = 0, sgprs = 0, lds_static = 0, scratch = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
+    uint64_t launch_count = 0;
 };
 
 #define GFHIP_TRY(ctx, call, what) do { if ((ctx)->check((call), (what))) return 1; } while (0)
@@ -429,7 +430,8 @@ static int launch(gfhip_kernel *k, const uint32_t steps) {
     params.push_back(&step_count);
 
     std::pair<hipEvent_t, hipEvent_t> ev;
-    if (ctx->timing) {
+    const bool timed = ctx->timing && (k->launch_count++ % ctx->timing) == 0;
+    if (timed) {
         if (!k->free_events.empty()) {
             ev = k->free_events.back();
             k->free_events.pop_back();
@@ -442,7 +444,7 @@ static int launch(gfhip_kernel *k, const uint32_t steps) {
     GFHIP_TRY(ctx, hipModuleLaunchKernel(k->function, k->grid, 1, 1, k->low.block_size, 1, 1,
                                          static_cast<unsigned int> (k->low.lds_bytes), ctx->stream,
                                          params.data(), nullptr), "hipModuleLaunchKernel");
-    if (ctx->timing) {
+    if (timed) {
         GFHIP_TRY(ctx, hipEventRecord(ev.second, ctx->stream), "hipEventRecord");
         k->events.push_back(ev);
     }
@@ -710,7 +712,7 @@ extern "C" int gfhip_kernel_get_info(const gfhip_kernel *k, struct gfhip_kernel_
 
 extern "C" int gfhip_enable_timing(gfhip_context *ctx, int enable) {
     if (!ctx) return 1;
-    ctx->timing = enable != 0;
+    ctx->timing = enable > 0 ? static_cast<unsigned int> (enable) : 0;
     return 0;
 }
 

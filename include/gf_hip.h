@@ -152,8 +152,10 @@ char *gfhip_generate_source(const void *gfir, size_t bytes, uint64_t *source_has
 void gfhip_free_string(char *text);
 
 /* Average duration in milliseconds of the launches of `kernel` recorded since
- * the last call (HIP events on the context's stream around every launch when
- * timing is enabled).  Used by bench.py for the roofline line. */
+ * the last call: HIP events on the context's stream around every `enable`-th
+ * launch of each kernel (1 = every launch, 0 = off; a pair of event records
+ * costs the stream 2-8 us, so a benchmark samples).  Used by bench.py for the
+ * roofline line. */
 int gfhip_enable_timing(gfhip_context *ctx, int enable);
 int gfhip_kernel_timing(gfhip_kernel *kernel, double *average_ms, uint64_t *launches);
 
