@@ -794,6 +794,7 @@ GF_PAIR2(gf_atan22, atan2f)
 //  fused launch, and the last tile, re-read this tile's own (cached) element.
                 s << ind << "unsigned long long ahead = (step + 1u == steps && g + stride < groups) ? g + stride : g;\n";
                 if (prefetch_position > 0) {
+                    define(static_cast<uint32_t> (prefetch_position - 1));
 //  Tie the address to the last gather's result, or the compiler hoists the loads to the top.
                     s << ind << "asm volatile(\"\" : \"+v\"(ahead) : \"v\"(" << N(static_cast<uint32_t> (prefetch_position - 1)) << "));\n";
                 }
