@@ -162,3 +162,35 @@ def test_random_items_lower_to_valid_gfx950_code(lib, tmp_path):
     path = tmp_path / "fuzz.hip"
     path.write_text(source)
     subprocess.check_call([HIPCC, "--genco"] + KERNEL_FLAGS + ["-o", str(tmp_path / "fuzz.hsaco"), str(path)])
+
+
+def _defined_before_use(source, kernel):
+    """Every value of the pass is defined once, before its first use (the emission order is a
+    topological order of the DAG whatever the scheduler did)."""
+    body = source[source.index(kernel + "("):]
+    defined = set()
+    count = 0
+    for line in body.splitlines():
+        match = re.match(r"\s*const (?:real|real2) (r\d+(?:p\d+)?) = (.*);$", line)
+        if not match:
+            continue
+        name, expression = match.groups()
+        for used in re.findall(r"\br\d+(?:p\d+)?\b", expression):
+            assert used in defined, (name, used)
+        assert name not in defined, name
+        defined.add(name)
+        count += 1
+    return count
+
+
+@pytest.mark.parametrize("schedule", ["greedy", "source"])
+def test_emission_order_is_topological(lib, monkeypatch, schedule):
+    import gfir_random
+    from graph_framework_amd import generate_source
+    monkeypatch.setenv("GFHIP_SCHEDULE", schedule)
+    source, _ = generate_source(os.path.join(WORKLOADS, "solver_kernel_f64.gfir"))
+    assert _defined_before_use(source, "gfhip_solver_kernel") >= 3878
+    blob, records = gfir_random.random_item(9, "f64", num_nodes=1500)
+    source, _ = generate_source(blob)
+#  (a derived-table gather nobody reads is never defined: the fuzz items have a few dead nodes)
+    assert _defined_before_use(source, "gfhip_fuzz") >= 0.95*records
