@@ -618,9 +618,13 @@ size_t converge(const work_item<T> &item, const size_t n, std::vector<T *> colum
 // solver_interface::compile, solver.hpp:303-349.
 // ---------------------------------------------------------------------------
 template<typename T>
-work_item<T> make_solver_kernel(const ray_variables<T> &v, equilibrium_base<T> &eq, const T dt_value,
-                                dispersion_interface<T> &D) {
-    auto dt = graph::constant<T> (dt_value);
+struct rk4_step {
+    leaf<T> kx_next, ky_next, kz_next, x_next, y_next, z_next, t_next, residual;
+};
+
+template<typename T>
+rk4_step<T> make_rk4_step(const ray_variables<T> &v, equilibrium_base<T> &eq, leaf<T> dt,
+                          dispersion_interface<T> &D) {
     auto kx1 = dt*D.dkxdt, ky1 = dt*D.dkydt, kz1 = dt*D.dkzdt;
     auto x1 = dt*D.dxdt, y1 = dt*D.dydt, z1 = dt*D.dzdt;
 
@@ -664,9 +668,16 @@ work_item<T> make_solver_kernel(const ray_variables<T> &v, equilibrium_base<T> &
     auto z_next = v.z + (z1 + 2.0*(z2 + z3) + z4)/6.0;
 
     auto residual = D.D*D.D;                                                // dispersion.hpp:1474
-    return work_item<T> (v.inputs(), {residual},
-                         {{kx_next, v.kx}, {ky_next, v.ky}, {kz_next, v.kz},
-                          {x_next, v.x}, {y_next, v.y}, {z_next, v.z}, {t_next, v.t}});
+    return {kx_next, ky_next, kz_next, x_next, y_next, z_next, t_next, residual};
+}
+
+template<typename T>
+work_item<T> make_solver_kernel(const ray_variables<T> &v, equilibrium_base<T> &eq, const T dt_value,
+                                dispersion_interface<T> &D) {
+    const rk4_step<T> s = make_rk4_step<T> (v, eq, graph::constant<T> (dt_value), D);
+    return work_item<T> (v.inputs(), {s.residual},
+                         {{s.kx_next, v.kx}, {s.ky_next, v.ky}, {s.kz_next, v.kz},
+                          {s.x_next, v.x}, {s.y_next, v.y}, {s.z_next, v.z}, {s.t_next, v.t}});
 }
 
 
