@@ -92,6 +92,8 @@ struct codegen_options {
     int division_fixup = -1;            ///< v_div_fixup after each shared-reciprocal quotient: 1 yes, 0 no, -1 auto
     bool prefetch_next_tile = false;    ///< EXPERIMENT: load the next grid-stride tile's inputs before computing this one
     uint32_t prefetch_min_gap = 600;    ///< ... after the latest gather followed by this many gather-free nodes
+    bool pipeline_tiles = false;        ///< EXPERIMENT (GFHIP_PIPELINE=1): software-pipelined tiles — the previous tile's
+                                        ///< stores and the next tile's loads are issued after the FIRST such gather
     uint32_t sched_barrier_every = 0;   ///< EXPERIMENT: __builtin_amdgcn_sched_barrier(0) every N nodes (0 = none)
     uint32_t park_prefetch = 50;        ///< issue a reload this many nodes before its first use (< window)
 
@@ -107,6 +109,10 @@ struct codegen_options {
         if (const char *e = std::getenv("GFHIP_PACKED")) o.packed_pairs = std::atoi(e);
         if (const char *e = std::getenv("GFHIP_DIV_FIXUP")) o.division_fixup = std::string(e) != "0" ? 1 : 0;
         if (const char *e = std::getenv("GFHIP_PREFETCH_NEXT")) o.prefetch_next_tile = std::string(e) == "1";
+        if (const char *e = std::getenv("GFHIP_PIPELINE")) {
+            o.pipeline_tiles = std::string(e) == "1";
+            if (o.pipeline_tiles) o.prefetch_next_tile = true;
+        }
         if (const char *e = std::getenv("GFHIP_PREFETCH_MIN_GAP")) o.prefetch_min_gap = static_cast<uint32_t> (std::atoi(e));
         if (const char *e = std::getenv("GFHIP_SCHED_BARRIER")) o.sched_barrier_every = static_cast<uint32_t> (std::atoi(e));
         if (const char *e = std::getenv("GFHIP_PARK_PREFETCH")) o.park_prefetch = static_cast<uint32_t> (std::atoi(e));
@@ -600,6 +606,16 @@ GF_PAIR2(gf_atan22, atan2f)
         for (size_t i = 0; i < it.symbols.size(); i++) {
             s << "    real next" << i << " = g < groups ? in" << i << "[g] : " << literal(0.0) << ";\n";
         }
+        if (opt.pipeline_tiles) {
+//  Results of the previous tile, stored one tile late (see the body).
+            s << "    bool have_pending = false;\n    unsigned long long pending_index = 0;\n";
+            for (size_t i = 0; i < it.symbols.size(); i++) {
+                if (out.input_written[i]) s << "    real pending_v" << i << " = " << literal(0.0) << ";\n";
+            }
+            for (size_t o = 0; o < it.outputs.size(); o++) {
+                s << "    real pending_o" << o << " = " << literal(0.0) << ";\n";
+            }
+        }
         s << "    for (; g < groups; g += stride) {\n";
     } else {
         s << "    for (unsigned long long g = blockIdx.x*static_cast<unsigned long long> (blockDim.x) + threadIdx.x; g < groups;\n"
@@ -779,7 +795,7 @@ GF_PAIR2(gf_atan22, atan2f)
                 const size_t next = k + 1 < gathers.size() ? gathers[k + 1] : it.code.size();
                 const size_t gap = next - gathers[k] - 1;
                 if (gap >= opt.prefetch_min_gap) {
-                    prefetch_position = gathers[k] + 1;
+                    if (!(opt.pipeline_tiles && satisfied)) prefetch_position = gathers[k] + 1;
                     satisfied = true;
                 } else if (!satisfied && gap > widest) {
                     widest = gap;
@@ -800,6 +816,19 @@ GF_PAIR2(gf_atan22, atan2f)
                 }
                 for (size_t k = 0; k < it.symbols.size(); k++) {
                     s << ind << "next" << k << " = in" << k << "[ahead];\n";
+                }
+                if (opt.pipeline_tiles) {
+//  The previous tile's results leave here: a store issued at the end of a pass would still be
+//  in flight at the next pass's first gather wait (vmcnt retires stores and loads in order).
+                    s << ind << "if (step == 0u && have_pending) {\n";
+                    for (size_t k = 0; k < it.symbols.size(); k++) {
+                        if (out.input_written[k]) s << ind << "    in" << k << "[pending_index] = pending_v" << k << ";\n";
+                    }
+                    for (size_t o = 0; o < it.outputs.size(); o++) {
+                        s << ind << "    out" << o << "[pending_index] = pending_o" << o << ";\n";
+                    }
+                    s << ind << "    have_pending = false;\n";
+                    s << ind << "}\n";
                 }
 //  ... and keep the scheduler from sinking them to the end of the pass.
                 s << ind << "__builtin_amdgcn_sched_barrier(0);\n";
@@ -1029,6 +1058,25 @@ GF_PAIR2(gf_atan22, atan2f)
             s << "            for (unsigned int e = 0; e < " << E << "u; e++) if (i + e < n) " << st.first << "[i + e] = " << st.second << "[e];\n";
         }
         s << "        }\n";
+    } else if (prefetch && opt.pipeline_tiles) {
+//  Keep this tile's results; they are stored from inside the next tile (or after the loop).
+        for (size_t i = 0; i < it.symbols.size(); i++) {
+            if (out.input_written[i]) s << "        pending_v" << i << " = v" << i << "[0];\n";
+        }
+        for (size_t o = 0; o < it.outputs.size(); o++) {
+            s << "        pending_o" << o << " = o" << o << "[0];\n";
+        }
+        s << "        pending_index = i;\n        have_pending = true;\n";
+        s << "    }\n";
+        s << "    if (have_pending) {\n";
+        for (size_t i = 0; i < it.symbols.size(); i++) {
+            if (out.input_written[i]) s << "        in" << i << "[pending_index] = pending_v" << i << ";\n";
+        }
+        for (size_t o = 0; o < it.outputs.size(); o++) {
+            s << "        out" << o << "[pending_index] = pending_o" << o << ";\n";
+        }
+        s << "    }\n}\n";
+        return;
     } else {
         for (auto &st : stores) {
             s << "        " << st.first << "[i] = " << st.second << "[0];\n";
