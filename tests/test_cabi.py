@@ -194,3 +194,14 @@ def test_emission_order_is_topological(lib, monkeypatch, schedule):
     source, _ = generate_source(blob)
 #  (a derived-table gather nobody reads is never defined: the fuzz items have a few dead nodes)
     assert _defined_before_use(source, "gfhip_fuzz") >= 0.95*records
+
+
+def test_mutated_items_never_crash_the_lowering(lib):
+    """tests/gfir_mutate.py: 400 truncated / bit-flipped / field-corrupted items are lowered or
+    rejected; the child process must exit normally."""
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gfir_mutate.py")
+    out = subprocess.run([sys.executable, script, "7", "400"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "rejected" in out.stdout
