@@ -46,11 +46,11 @@ struct item {
         const uint8_t *p = static_cast<const uint8_t *> (data);
         size_t pos = 0;
         auto take = [&] (void *dst, const size_t n) -> bool {
-            if (pos + n > bytes) {
+            if (n > bytes || pos > bytes - n) {
                 error = "GFIR item is truncated";
                 return false;
             }
-            std::memcpy(dst, p + pos, n);
+            if (n) std::memcpy(dst, p + pos, n);
             pos += n;
             return true;
         };

@@ -205,3 +205,21 @@ def test_mutated_items_never_crash_the_lowering(lib):
     out = subprocess.run([sys.executable, script, "7", "400"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "rejected" in out.stdout
+
+
+def test_lowering_under_address_and_ub_sanitizers(tmp_path):
+    """The parser, scheduler and lowering (host code, no HIP runtime) built with
+    -fsanitize=address,undefined: every exported workload and 600 mutated items."""
+    import glob
+    import subprocess
+    from conftest import ROOT
+    binary = str(tmp_path / "lowering_sanitize")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined",
+                           "-fno-sanitize-recover=undefined", "-o", binary,
+                           os.path.join(ROOT, "tests", "lowering_sanitize.cpp")])
+    workloads = sorted(glob.glob(os.path.join(WORKLOADS, "*.gfir")))
+    out = subprocess.run([binary] + workloads + ["--mutate", "5", "300", os.path.join(WORKLOADS, "loss_kernel_kx_f64.gfir"),
+                                                 "--mutate", "6", "300", os.path.join(WORKLOADS, "korc_step_f32.gfir")],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.startswith("lowered")
