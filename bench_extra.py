@@ -147,6 +147,45 @@ def stream7(dtype, n=10000000, steps=50):
                                           "frac": achieved/8000.0}}
 
 
+def trajectory(n=1000000, steps=400, every=100):
+    """SURVEY 8(f) row 1: the step loop with solver_interface::write_step every `every` steps
+    (snapshot D2D on the compute stream, D2H on a second stream, HDF5 append on a writer thread)."""
+    import tempfile
+    import torch
+    from graph_framework_amd.output import TrajectoryWriter
+    from graph_framework_amd.xrays import Rk4ColdPlasmaEfit
+    state = {k: np.full(n, v) for k, v in dict(t=0.0, w=500.0, x=2.5, y=0.0, z=0.0, kx=-600.0, ky=0.0, kz=0.0).items()}
+    solve = Rk4ColdPlasmaEfit(state, device_state=True)
+    solve.init("kx")
+    solve.compile()
+    for _ in range(10):
+        solve.step()
+    torch.cuda.synchronize()
+    start = time.perf_counter()
+    for _ in range(steps):
+        solve.step()
+    torch.cuda.synchronize()
+    plain = time.perf_counter() - start
+    with tempfile.TemporaryDirectory() as directory:
+        path = os.path.join(directory, "result0.nc")
+        writer = TrajectoryWriter(solve, path)
+        start = time.perf_counter()
+        for step in range(steps):
+            solve.step()
+            if (step + 1) % every == 0:
+                writer.write_step()
+        torch.cuda.synchronize()
+        loop = time.perf_counter() - start
+        writer.close()
+        total = time.perf_counter() - start
+        size = os.path.getsize(path)
+    return {"workload": "solver_kernel 1e6 rays with write_step every %d steps (%d records)" % (every, steps//every),
+            "value": n*steps/loop, "unit": "ray-steps/s", "without_output": n*steps/plain,
+            "seconds_until_file_closed": total, "file_bytes": size,
+            "note": "write_step joins the previous writer thread first (solver.hpp:419), so the loop is throttled "
+                    "only if a record takes longer to write than `every` steps take to compute"}
+
+
 def fused(n=1000000, steps=200, per_launch=10):
     """RK4 with `per_launch` steps fused into one launch (xrays_bench's SUB_STEPS = 10)."""
     from graph_framework_amd.xrays import Rk4ColdPlasmaEfit
@@ -178,6 +217,8 @@ if __name__ == "__main__":
         out = stream(what.split("_")[1])
     elif what == "solver_f32":
         out = solver_f32()
+    elif what == "trajectory":
+        out = trajectory()
     elif what == "fused":
         out = fused()
     else:
