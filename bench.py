@@ -124,6 +124,9 @@ def main():
     parser.add_argument("--steps", type=int, default=200)
     parser.add_argument("--warmup", type=int, default=10)
     parser.add_argument("--rays-per-gpu", type=int, default=1000000)
+    parser.add_argument("--total-rays", type=int, default=0,
+                        help="strong scaling (BASELINE configs[3]): a fixed ensemble split over the ranks as the "
+                             "reference splits it over device threads (xrays_bench.cpp:38-51); overrides --rays-per-gpu")
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--backend", choices=["nccl", "gloo"], default=None,
                         help="torch.distributed backend (default nccl = RCCL); gloo + --share-gpu rehearses "
@@ -137,7 +140,7 @@ def main():
 
     import torch
     from graph_framework_amd import distributed as gfd
-    from graph_framework_amd.xrays import Rk4ColdPlasmaEfit, STATE, workload
+    from graph_framework_amd.xrays import Rk4ColdPlasmaEfit, STATE, shard_bounds, workload
 
     rank, world, local_rank = gfd.init(args.backend, device_index=0 if args.share_gpu else None)
     if world != args.gpus:
@@ -146,8 +149,13 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
 
-    n_local = args.rays_per_gpu
-    total = n_local*world
+    if args.total_rays > 0:
+        begin, end = shard_bounds(args.total_rays, world, rank)
+        n_local = end - begin
+        total = args.total_rays
+    else:
+        n_local = args.rays_per_gpu
+        total = n_local*world
 
 #  Rank 0 reads the work items (they carry the equilibrium tables); RCCL broadcast to the rest.
     items = {}
@@ -234,7 +242,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1.0e3*elapsed/args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.total_rays > 0 else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
