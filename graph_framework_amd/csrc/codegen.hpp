@@ -25,6 +25,11 @@
 ///    psi pack (1.5 MB) stays L2 resident (4 MiB per XCD);
 ///  * `steps` passes can run inside one launch with the state kept in
 ///    registers (the reference launches once per step, solver.hpp:382).
+///
+///  Pieces: options.hpp (knobs, cache hash), schedule.hpp (emission order),
+///  tables.hpp (compaction, packs, LDS staging), parking.hpp (values that wait
+///  in LDS), prelude.hpp (device helpers: division, window check, pow), and
+///  lower() below, which writes the kernel text.
 //------------------------------------------------------------------------------
 #ifndef gfhip_codegen_hpp
 #define gfhip_codegen_hpp
@@ -43,21 +48,15 @@
 #include <vector>
 
 #include <fstream>
+
 #include "gfir_item.hpp"
+#include "options.hpp"
+#include "parking.hpp"
+#include "prelude.hpp"
 #include "schedule.hpp"
+#include "tables.hpp"
 
 namespace gfhip {
-
-///  All tables of one shape, packed `[cell][column]`.
-struct pack {
-    uint32_t rows = 1, cols = 1;
-    std::vector<uint32_t> tables;       ///< table index per column
-    uint32_t stride = 0;                ///< columns padded to an even count (16 B alignment of a cell)
-    bool in_lds = false;
-
-    size_t cells() const { return static_cast<size_t> (rows)*cols; }
-    size_t elements() const { return cells()*stride; }
-};
 
 struct lowered {
     std::string source;
@@ -73,72 +72,6 @@ struct lowered {
     bool has_converge = false;          ///< the module also holds `<name>_converge`
     uint64_t hash = 0;
 };
-
-struct codegen_options {
-    size_t lds_budget = 64*1024;        ///< bytes of LDS the staged packs may use per workgroup
-    uint32_t block_size = 256;
-    uint32_t waves_per_simd = 0;        ///< second __launch_bounds__ argument (0 = let the compiler decide)
-    bool shared_reciprocal = true;      ///< fp64 divisions by one denominator share its refined reciprocal
-    bool pow_three_halves = true;       ///< fp64 pow(x, 1.5) as a compensated x*sqrt(x)
-    bool compact_tables = true;         ///< store only tables that are not an exact multiple of another
-    bool park_in_lds = true;            ///< very long-lived values wait in LDS instead of AGPRs/scratch (GFHIP_PARK=0 disables)
-    uint32_t park_min_range = 1500;     ///< park values whose live range exceeds this many nodes ...
-    uint32_t park_window = 100;         ///< ... uses closer than this share one reload
-    uint32_t park_max_slots = 32;       ///< LDS slots of block_size elements each
-    bool schedule_for_pressure = true;  ///< emit in the pressure-aware order of schedule.hpp (GFHIP_SCHEDULE=source: item order)
-    uint32_t elements_per_lane = 0;     ///< rays per lane (0 = auto = 1; 2/4 = vector loads, GFHIP_ELEMENTS_PER_LANE)
-    int packed_pairs = -1;              ///< fp32 items: two rays per lane as a float2, arithmetic on v_pk_*_f32
-                                        ///< (-1 = auto, GFHIP_PACKED=0/1)
-    int division_fixup = -1;            ///< v_div_fixup after each shared-reciprocal quotient: 1 yes, 0 no, -1 auto
-    bool prefetch_next_tile = false;    ///< EXPERIMENT: load the next grid-stride tile's inputs before computing this one
-    uint32_t prefetch_min_gap = 600;    ///< ... after the latest gather followed by this many gather-free nodes
-    bool pipeline_tiles = false;        ///< EXPERIMENT (GFHIP_PIPELINE=1): software-pipelined tiles — the previous tile's
-                                        ///< stores and the next tile's loads are issued after the FIRST such gather
-    uint32_t sched_barrier_every = 0;   ///< EXPERIMENT: __builtin_amdgcn_sched_barrier(0) every N nodes (0 = none)
-    uint32_t park_prefetch = 50;        ///< issue a reload this many nodes before its first use (< window)
-
-//  Environment overrides (they change the generated text, hence the cache key).
-    static codegen_options from_environment() {
-        codegen_options o;
-        if (const char *e = std::getenv("GFHIP_DIVISION")) o.shared_reciprocal = std::string(e) != "ieee";
-        if (const char *e = std::getenv("GFHIP_PARK")) o.park_in_lds = std::string(e) != "0";
-        if (const char *e = std::getenv("GFHIP_PARK_MIN_RANGE")) o.park_min_range = static_cast<uint32_t> (std::atoi(e));
-        if (const char *e = std::getenv("GFHIP_PARK_WINDOW")) o.park_window = static_cast<uint32_t> (std::atoi(e));
-        if (const char *e = std::getenv("GFHIP_SCHEDULE")) o.schedule_for_pressure = std::string(e) != "source";
-        if (const char *e = std::getenv("GFHIP_ELEMENTS_PER_LANE")) o.elements_per_lane = static_cast<uint32_t> (std::atoi(e));
-        if (const char *e = std::getenv("GFHIP_PACKED")) o.packed_pairs = std::atoi(e);
-        if (const char *e = std::getenv("GFHIP_DIV_FIXUP")) o.division_fixup = std::string(e) != "0" ? 1 : 0;
-        if (const char *e = std::getenv("GFHIP_PREFETCH_NEXT")) o.prefetch_next_tile = std::string(e) == "1";
-        if (const char *e = std::getenv("GFHIP_PIPELINE")) {
-            o.pipeline_tiles = std::string(e) == "1";
-            if (o.pipeline_tiles) o.prefetch_next_tile = true;
-        }
-        if (const char *e = std::getenv("GFHIP_PREFETCH_MIN_GAP")) o.prefetch_min_gap = static_cast<uint32_t> (std::atoi(e));
-        if (const char *e = std::getenv("GFHIP_SCHED_BARRIER")) o.sched_barrier_every = static_cast<uint32_t> (std::atoi(e));
-        if (const char *e = std::getenv("GFHIP_PARK_PREFETCH")) o.park_prefetch = static_cast<uint32_t> (std::atoi(e));
-        if (const char *e = std::getenv("GFHIP_PARK_MAX_SLOTS")) o.park_max_slots = static_cast<uint32_t> (std::atoi(e));
-        if (const char *e = std::getenv("GFHIP_COMPACT_TABLES")) o.compact_tables = std::string(e) != "0";
-        if (const char *e = std::getenv("GFHIP_POW")) o.pow_three_halves = std::string(e) != "libm";
-        if (const char *e = std::getenv("GFHIP_WAVES_PER_SIMD")) o.waves_per_simd = static_cast<uint32_t> (std::atoi(e));
-        if (const char *e = std::getenv("GFHIP_BLOCK_SIZE")) o.block_size = static_cast<uint32_t> (std::atoi(e));
-        if (const char *e = std::getenv("GFHIP_LDS_BUDGET")) o.lds_budget = static_cast<size_t> (std::atol(e));
-        return o;
-    }
-};
-
-inline uint64_t fnv1a(const std::string &s) {
-    uint64_t h = 1469598103934665603ull;
-    for (unsigned char c : s) {
-        h ^= c;
-        h *= 1099511628211ull;
-    }
-    return h;
-}
-
-///  Flags the lowering relies on; part of the cache key.
-inline const char *compile_flags() {
-    return "-O3 -ffp-contract=off --offload-arch=gfx950";
-}
 
 //------------------------------------------------------------------------------
 ///  @brief Lower one item.
@@ -186,115 +119,14 @@ inline lowered lower(const item &original, const codegen_options &opt = codegen_
         out.input_written[s.input] = true;
     }
 
-//  Table compaction.  reduce() folds constants into coefficient tables at graph-build time
-//  (arithmetic.hpp:192-247), so a kernel gathers many tables that are a constant times
-//  another one (45 psi tables, 16 independent).  Where fl(k*parent[c]) == table[c] holds for
-//  EVERY cell (checked here, in the item's precision) the table is not stored: its gather
-//  becomes k*(gather of the parent) — the same bits, one multiply instead of a load, and the
-//  2-D pack of the RK4 kernel shrinks from 360 B to one 128 B line per cell.
-    std::vector<int> parent(it.tables.size(), -1);
-    std::vector<double> factor(it.tables.size(), 1.0);
-    if (opt.compact_tables) {
-        auto derive = [&] (const table &from, const table &to, double &k_out) -> bool {
-            if (from.rows != to.rows || from.cols != to.cols) return false;
-            size_t arg = 0;
-            double best = 0.0;
-            for (size_t c = 0; c < from.data.size(); c++) {
-                if ((from.data[c] == 0.0) != (to.data[c] == 0.0)) return false;
-                if (std::fabs(from.data[c]) > best) { best = std::fabs(from.data[c]); arg = c; }
-            }
-            if (best == 0.0) return false;
-            const double k0 = to.data[arg]/from.data[arg];
-            std::vector<double> candidates = {k0, std::nextafter(k0, 1.0E300), std::nextafter(k0, -1.0E300)};
-            for (int q = 1; q <= 12; q++) {
-                const double p = std::nearbyint(k0*q);
-                if (p != 0.0 && std::fabs(p/q - k0) <= 1.0E-12*std::fabs(k0)) candidates.push_back(p/q);
-            }
-            for (const double k : candidates) {
-                bool exact = true;
-                for (size_t c = 0; c < from.data.size() && exact; c++) {
-                    if (f64) {
-                        exact = k*from.data[c] == to.data[c];
-                    } else {
-                        exact = static_cast<float> (k)*static_cast<float> (from.data[c]) == static_cast<float> (to.data[c]) &&
-                                static_cast<double> (static_cast<float> (k)) == k;
-                    }
-                }
-                if (exact) { k_out = k; return true; }
-            }
-            return false;
-        };
-//  First pass: a table is derived from an EARLIER table (stored or itself derived; parents
-//  always have a smaller index, so there are no cycles).
-        for (size_t j = 0; j < it.tables.size(); j++) {
-            for (size_t i = 0; i < j; i++) {
-                double k;
-                if (derive(it.tables[i], it.tables[j], k)) {
-                    parent[j] = static_cast<int> (i);
-                    factor[j] = k;
-                    break;
-                }
-            }
-        }
-//  Second pass: a still-stored table that is an exact multiple of a LATER stored table (e.g.
-//  3*c met before c) is re-parented to it; only stored tables become parents here, and they
-//  keep no parent of a smaller index, so chains stay acyclic.
-        for (size_t j = 0; j < it.tables.size(); j++) {
-            if (parent[j] >= 0) continue;
-            for (size_t i = j + 1; i < it.tables.size(); i++) {
-                if (parent[i] >= 0) continue;
-                double k;
-                if (derive(it.tables[i], it.tables[j], k)) {
-                    parent[j] = static_cast<int> (i);
-                    factor[j] = k;
-                    break;
-                }
-            }
-        }
-    }
+    const table_layout layout = layout_tables(it, opt);
+    const std::vector<int> &parent = layout.parent;
+    const std::vector<double> &factor = layout.factor;
+    const std::vector<uint32_t> &table_pack = layout.table_pack, &table_column = layout.table_column;
     out.table_parent = parent;
     out.table_factor = factor;
-
-//  Packs: one per table shape, one column per STORED table, in table order.
-    std::map<std::pair<uint32_t, uint32_t>, size_t> pack_of_shape;
-    std::vector<uint32_t> table_pack(it.tables.size()), table_column(it.tables.size());
-    for (size_t t = 0; t < it.tables.size(); t++) {
-        const auto shape = std::make_pair(it.tables[t].rows, it.tables[t].cols);
-        auto found = pack_of_shape.find(shape);
-        if (found == pack_of_shape.end()) {
-            pack p;
-            p.rows = shape.first;
-            p.cols = shape.second;
-            out.packs.push_back(p);
-            found = pack_of_shape.insert({shape, out.packs.size() - 1}).first;
-        }
-        pack &p = out.packs[found->second];
-        table_pack[t] = static_cast<uint32_t> (found->second);
-        if (parent[t] >= 0) continue;
-        table_column[t] = static_cast<uint32_t> (p.tables.size());
-        p.tables.push_back(static_cast<uint32_t> (t));
-    }
-    size_t lds_used = 0;
-    for (auto &p : out.packs) {
-        p.stride = static_cast<uint32_t> ((p.tables.size() + 1)/2*2);
-    }
-//  Stage the smallest packs first while they fit the budget.
-    {
-        std::vector<size_t> order(out.packs.size());
-        for (size_t i = 0; i < order.size(); i++) order[i] = i;
-        for (size_t i = 0; i < order.size(); i++) {
-            for (size_t j = i + 1; j < order.size(); j++) {
-                if (out.packs[order[j]].elements() < out.packs[order[i]].elements()) std::swap(order[i], order[j]);
-            }
-        }
-        for (size_t i : order) {
-            const size_t bytes = out.packs[i].elements()*esize;
-            if (lds_used + bytes <= opt.lds_budget) {
-                out.packs[i].in_lds = true;
-                lds_used += (bytes + 15)/16*16;
-            }
-        }
-    }
+    out.packs = layout.packs;
+    size_t lds_used = layout.lds_used;
     out.block_size = opt.block_size;
 
 //  Rays per lane.  A lane that owns ONE 4- or 8-byte element issues 4/8-byte loads; small
@@ -316,94 +148,9 @@ inline lowered lower(const item &original, const codegen_options &opt = codegen_
     if (packed) elements = 2;
     out.elements = elements;
 
-//  LDS parking.  Measured on MI355X (1e6 rays, ms per RK4 step): none 0.359 (340 B/lane of
-//  scratch = 350 MB of HBM writes per step); every value with range > 300 nodes 0.46-0.55
-//  (each LDS op costs the single in-order wave an issue slot, like the move it replaces);
-//  only values with range > 1500 nodes, <= 32 slots: 0.317 and NO scratch — the default.
-//  The RK4 item keeps ~150 fp64 values alive (stage results, the state, shared
-//  sub-expressions of the seven partials); at 512 registers per lane the compiler shuttles
-//  them through AGPRs (two VALU moves each way) and scratch (HBM write traffic).  Values
-//  whose live range is long and whose uses cluster are instead written once to a per-lane
-//  LDS slot (`park[slot*block + lane]`, conflict free, LDS pipe instead of VALU) and read
-//  back at the first use of every later cluster.  Pure data movement: bits unchanged.
     const size_t node_count = it.code.size();
-    struct park_plan {
-        bool parked = false;
-        uint32_t slot = 0;
-        std::map<size_t, uint32_t> reload_at;       ///< position -> cluster number
-    };
-    std::vector<park_plan> plan(node_count);
     uint32_t park_slots = 0;
-//  A workgroup may declare all 160 KiB of a CU's LDS; stay inside it.
-    const size_t lds_capacity = 160*1024;
-    const size_t slot_bytes = static_cast<size_t> (opt.block_size)*esize;
-    const uint32_t slot_limit = lds_used < lds_capacity
-                              ? static_cast<uint32_t> (std::min<size_t> (opt.park_max_slots, (lds_capacity - lds_used)/slot_bytes))
-                              : 0;
-    if (opt.park_in_lds && slot_limit > 0 && elements == 1) {
-        std::vector<std::vector<size_t>> uses(node_count);
-        auto arity = [] (const uint32_t op) -> int {
-            switch (op) {
-                case GFIR_CONST: case GFIR_INPUT: return 0;
-                case GFIR_FMA: return 3;
-                case GFIR_SQRT: case GFIR_POWI: case GFIR_SIN: case GFIR_COS: case GFIR_EXP: case GFIR_LOG:
-                case GFIR_GATHER1: return 1;
-                default: return 2;
-            }
-        };
-        for (size_t i = 0; i < node_count; i++) {
-            const gfir_instruction &c = it.code[i];
-            const uint32_t operands[3] = {c.a, c.b, c.c};
-            for (int k = 0; k < arity(c.op); k++) {
-                if (uses[operands[k]].empty() || uses[operands[k]].back() != i) uses[operands[k]].push_back(i);
-            }
-        }
-        for (auto &st : it.setters) uses[st.value].push_back(node_count);
-        for (auto o : it.outputs) uses[o].push_back(node_count);
-
-        struct candidate { size_t def, last; uint32_t value; };
-        std::vector<candidate> candidates;
-        for (size_t v = 0; v < node_count; v++) {
-            const uint32_t op = it.code[v].op;
-            if (op == GFIR_CONST || op == GFIR_INPUT || uses[v].empty()) continue;
-            if (uses[v].back() - v < opt.park_min_range) continue;
-            size_t previous = v;
-            uint32_t cluster = 0;
-            std::map<size_t, uint32_t> reloads;
-            const size_t prefetch = opt.park_prefetch < opt.park_window ? opt.park_prefetch : opt.park_window - 1;
-            for (const size_t u : uses[v]) {
-                if (u - previous > opt.park_window) {
-//  Issue the LDS read `prefetch` nodes ahead of the first use of the cluster (there is no
-//  other use of the value in that gap: clusters are further apart than the window).
-                    reloads[u - prefetch] = ++cluster;
-                }
-                previous = u;
-            }
-            if (reloads.empty()) continue;
-            plan[v].reload_at = reloads;
-            candidates.push_back({v, uses[v].back(), static_cast<uint32_t> (v)});
-        }
-//  Linear-scan slot allocation in definition order; a slot is free after the last reload.
-        std::vector<size_t> slot_free_at;
-        for (auto &c : candidates) {
-            const size_t last_reload = plan[c.value].reload_at.rbegin()->first;
-            uint32_t slot = static_cast<uint32_t> (slot_free_at.size());
-            for (uint32_t k = 0; k < slot_free_at.size(); k++) {
-                if (slot_free_at[k] < c.def) { slot = k; break; }
-            }
-            if (slot == slot_free_at.size()) {
-                if (slot_free_at.size() >= slot_limit) {
-                    plan[c.value].reload_at.clear();
-                    continue;
-                }
-                slot_free_at.push_back(0);
-            }
-            slot_free_at[slot] = last_reload;
-            plan[c.value].parked = true;
-            plan[c.value].slot = slot;
-        }
-        park_slots = static_cast<uint32_t> (slot_free_at.size());
-    }
+    const std::vector<park_plan> plan = plan_parking(it, opt, lds_used, esize, elements, park_slots);
     const size_t park_offset = lds_used;
     lds_used += static_cast<size_t> (park_slots)*opt.block_size*esize;
     out.lds_bytes = lds_used;
@@ -411,98 +158,8 @@ inline lowered lower(const item &original, const codegen_options &opt = codegen_
 
     std::ostringstream s;
     out.kernel_name = "gfhip_" + it.name;
-    s << "// Generated by graph_framework_amd (GFIR -> gfx950).  Work item \"" << it.name << "\": "
-      << it.code.size() << " nodes, " << it.tables.size() << " tables in " << out.packs.size() << " packs.\n";
-//  hipRTC predefines the runtime declarations; its include search does not always reach the
-//  ROCm headers (a stand-alone process on a box whose /opt/rocm hipRTC has no header path).
-    s << "#if !defined(__HIPCC_RTC__)\n#include <hip/hip_runtime.h>\n#endif\n";
-    s << "typedef " << real << " real;\n";
+    emit_prelude(s, it, opt, out.packs.size(), packed);
     const bool use_shared = opt.shared_reciprocal;
-//  v_div_fixup only acts on special operands.  Inside the checked window (finite non-zero
-//  denominator, finite results) dropping it changes exactly one thing: a quotient with
-//  numerator -0 and a positive denominator comes out +0 instead of -0.  A zero of either sign
-//  is the same value to every later operation except a division by it (non-finite, flagged)
-//  and atan2, so the fixup (680 of 7700 VALU instructions in the RK4 step, 8 % of its time)
-//  is kept only for items that contain an atan2 node.
-    bool fixup = opt.division_fixup == 1;
-    if (opt.division_fixup < 0) {
-        fixup = false;
-        for (auto &c : it.code) {
-            if (c.op == GFIR_ATAN2) fixup = true;
-        }
-    }
-//  Window check of the denominators: |d| is tracked through an fp32 image that is monotonic in
-//  |d| — |d| itself for float, the high dword of a double read as a float (sign, 11 exponent
-//  bits, 20 mantissa bits) — so that one v_maximum3_f32 / v_minimum3_f32 (gfx950, abs modifiers
-//  free) folds TWO denominators into the running extreme: 1 VALU instruction per denominator
-//  instead of 3 with fp64 fmax/fmin.  Both are the IEEE-754-2019 NaN-propagating forms: a
-//  high dword that reads as a float NaN (|d| >= 2^1017, infinity, NaN) poisons the accumulator
-//  and fails the final comparison, like any other value outside the window.
-    s << R"(
-__device__ __forceinline__ float gf_magnitude(const float d) { return __builtin_fabsf(d); }
-__device__ __forceinline__ float gf_magnitude(const double d) {
-    return __builtin_fabsf(__builtin_bit_cast(float, static_cast<unsigned int> (__builtin_bit_cast(unsigned long long, d) >> 32)));
-}
-)";
-    if (!f64) {
-        s << (fixup ? "#define GF_FIXUP(q, d, n) __builtin_amdgcn_div_fixupf(q, d, n)\n"
-                    : "#define GF_FIXUP(q, d, n) (q)\n");
-        s << R"(
-// fp32 division as hipcc lowers it (denormals on): scale, r = rcp(d) + one Newton step,
-// q = n*r refined by two residual steps, a third residual folded in by div_fmas, un-scale,
-// fixup.  Shared per denominator like the fp64 form below; identical bits while no scaling is
-// needed: hardware scales when 1/d, n/d or the residual would leave the normal range, i.e.
-// |d| outside [2^-126, 2^126], |n/d| outside the normal range, or 0 < |n| < 2^-102.  Checked per
-// pass: |d| in [2^-100, 2^100] and finite results; numerators below 2^-102 are not checked
-// (their quotients may differ in the last bit).
-__device__ __forceinline__ float gf_rcp(const float d) {
-    const float r = __builtin_amdgcn_rcpf(d);
-    const float e = __builtin_fmaf(-d, r, 1.0f);
-    return __builtin_fmaf(e, r, r);
-}
-__device__ __forceinline__ float gf_div(const float n, const float d, const float r) {
-    const float q0 = n*r;
-    const float e0 = __builtin_fmaf(-d, q0, n);
-    const float q1 = __builtin_fmaf(e0, r, q0);
-    const float e1 = __builtin_fmaf(-d, q1, n);
-    return GF_FIXUP(__builtin_fmaf(e1, r, q1), d, n);
-}
-)";
-    }
-    if (f64) {
-        s << (fixup ? "#define GF_FIXUP(q, d, n) __builtin_amdgcn_div_fixup(q, d, n)\n"
-                    : "#define GF_FIXUP(q, d, n) (q)\n");
-        s << R"(
-// IEEE fp64 division as hipcc lowers it is: scale, r = rcp(d) refined by two Newton steps,
-// q = n*r, e = fma(-d, q, n), q' = fma(e, r, q), un-scale, fix special values.  A work item
-// divides many numerators by few denominators (680 divisions, 82 denominators in the RK4
-// kernel), so the refinement is done once per denominator.  Without the scaling the sequence
-// is the same instruction for instruction, hence bit-identical, while d stays in
-// [2^-500, 2^500]; lanes that leave that window are recomputed with the compiler's division.
-__device__ __forceinline__ double gf_rcp(const double d) {
-    double r = __builtin_amdgcn_rcp(d);
-    double e = __builtin_fma(-d, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-d, r, 1.0);
-    return __builtin_fma(r, e, r);
-}
-__device__ __forceinline__ double gf_div(const double n, const double d, const double r) {
-    const double q = n*r;
-    const double e = __builtin_fma(-d, q, n);
-    return GF_FIXUP(__builtin_fma(e, r, q), d, n);
-}
-// pow(x, 1.5) = x*sqrt(x) with the rounding error of the square root carried into the
-// product (s + t ~ sqrt(x) to ~100 bits), i.e. rounded once from the exact value almost
-// always, as glibc's pow is; ocml's pow is within 1 ulp only and costs ~10x more.
-__device__ __forceinline__ double gf_pow_three_halves(const double x) {
-    const double s = __builtin_sqrt(x);
-    const double t = __builtin_fma(-s, s, x)*(0.5*__builtin_amdgcn_rcp(s));
-    const double p = x*s;
-    const double c = __builtin_fma(x, s, -p) + x*t;
-    return (x > 0.0 && x < __builtin_inf()) ? p + c : pow(x, 1.5);
-}
-)";
-    }
 //  Two entry points per item: `<name>` runs `steps` passes; `<name>_converge` (items with a
 //  setter and an output, one ray per lane) runs the stall loop of workflow.hpp:179-205 PER RAY
 //  inside the launch — every lane iterates on its own residual, a wavefront leaves the loop
@@ -511,34 +168,6 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
 //  rays are identical (the benchmark) and is offered as gfhip_converge_per_ray.
     const bool has_converge = !it.setters.empty() && !it.outputs.empty() && elements == 1 &&
                               it.code.size() <= 1500;
-    if (packed) {
-        s << R"(
-typedef float real2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ real2 gf_fma2(const real2 a, const real2 b, const real2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ real2 gf_rcp(const real2 d) {
-    const real2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
-    const real2 e = gf_fma2(-d, r, (real2)(1.0f));
-    return gf_fma2(e, r, r);
-}
-__device__ __forceinline__ real2 gf_div(const real2 n, const real2 d, const real2 r) {
-    const real2 q0 = n*r;
-    const real2 e0 = gf_fma2(-d, q0, n);
-    const real2 q1 = gf_fma2(e0, r, q0);
-    const real2 e1 = gf_fma2(-d, q1, n);
-    const real2 q2 = gf_fma2(e1, r, q1);
-    return real2{GF_FIXUP(q2.x, d.x, n.x), GF_FIXUP(q2.y, d.y, n.y)};
-}
-#define GF_PAIR1(name, fn) __device__ __forceinline__ real2 name(const real2 a) { return real2{fn(a.x), fn(a.y)}; }
-#define GF_PAIR2(name, fn) __device__ __forceinline__ real2 name(const real2 a, const real2 b) { return real2{fn(a.x, b.x), fn(a.y, b.y)}; }
-GF_PAIR1(gf_sqrt2, __builtin_sqrtf)
-GF_PAIR1(gf_sin2, sinf)
-GF_PAIR1(gf_cos2, cosf)
-GF_PAIR1(gf_exp2, expf)
-GF_PAIR1(gf_log2, logf)
-GF_PAIR2(gf_pow2, powf)
-GF_PAIR2(gf_atan22, atan2f)
-)";
-    }
     out.has_converge = has_converge;
     const std::string VT = packed ? "real2" : "real";         // type of a value of the pass
     auto emit_kernel = [&] (const bool converge) {
@@ -743,7 +372,7 @@ GF_PAIR2(gf_atan22, atan2f)
             auto found = reloads_at_position.find(position);
             if (found == reloads_at_position.end()) return;
             for (const uint32_t v : found->second) {
-                name[v] = "r" + std::to_string(v) + "p" + std::to_string(plan[v].reload_at[position]);
+                name[v] = "r" + std::to_string(v) + "p" + std::to_string(plan[v].reload_at.at(position));
                 s << ind << "const real " << name[v] << " = park_read[" << plan[v].slot*out.block_size << "u];\n";
             }
         };
