@@ -47,3 +47,9 @@ def random_plasma_state(n, seed, dtype=np.float64):
 
 
 STATE = ("t", "w", "x", "y", "z", "kx", "ky", "kz")
+
+
+@pytest.fixture(scope="session")
+def golden_ref():
+    """tests/golden/ref_golden.npz: records written by the reference's own graph layer."""
+    return np.load(os.path.join(GOLDEN, "ref_golden.npz"))
