@@ -214,20 +214,6 @@ def main():
         torch.cuda.synchronize()
         gather_seconds = gfd.max_over_ranks(time.perf_counter() - t0)
 
-#  Outside the timed region, for the record: the same steps issued ten per launch (the state
-#  stays in registers between passes; bit-identical, tests/test_gpu_workflows.py).  `value` above
-#  is the reference's one launch per step().
-    fused_rate = None
-    if world == 1 and args.steps >= 10:
-        solve.work.context.enable_timing(False)
-        solve.step(10)
-        torch.cuda.synchronize()
-        fused_start = time.perf_counter()
-        for _ in range(args.steps//10):
-            solve.step(10)
-        torch.cuda.synchronize()
-        fused_rate = total*(args.steps//10)*10/(time.perf_counter() - fused_start)
-
     if rank == 0:
         info = solve.solver.kernel.info()
         value = total*args.steps/elapsed
@@ -268,9 +254,6 @@ def main():
             "value_with_sync_host": total*args.steps/(elapsed + sync_elapsed),
             "newton_iterations": solve.newton_iterations,
         }
-        if fused_rate is not None:
-            line["ten_steps_per_launch"] = {"value": fused_rate, "unit": "ray-steps/s",
-                                            "note": "not the metric: same arithmetic, one launch per 10 steps"}
         if gather_seconds is not None:
             line["all_gather_seconds"] = gather_seconds
         if world == 1 and not args.no_cpu_baseline:
