@@ -177,6 +177,7 @@ extern "C" gfhip_context *gfhip_create_context(int index, void *stream) {
         hipMalloc(reinterpret_cast<void **> (&ctx->device_scalar), sizeof(unsigned long long)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **> (&ctx->host_scalar), sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
         creation_error = "cannot allocate reduction scalars";
+        gfhip_destroy_context(ctx.release());                  // frees whatever was allocated
         return nullptr;
     }
     return ctx.release();
