@@ -175,3 +175,38 @@ def test_full_size_ensembles_through_size_independent_properties(golden_ref):
         assert np.array_equal(whole[k][:cut], first[k], equal_nan=True), k
         assert np.array_equal(whole[k][cut:], second[k], equal_nan=True), k
     assert np.isfinite(whole["x"]).all() and np.ptp(whole["kz"]) > 1.0      # a genuinely incoherent beam
+
+
+def test_incoherent_beam_500_steps_including_rays_that_blow_up():
+    """The CLI example's beam (graph_driver/xrays.cpp:392-399) followed for 500 RK4 steps: every ray
+    bit-identical to the oracle's evaluation of the reference DAG.  A few rays of this beam are
+    driven to non-finite values by the reference graph itself (the residual grows to 1e49 first);
+    they must become non-finite at the same step on both sides, and the context must raise its
+    status flag (bit 0: non-finite results or a denominator outside the shared-reciprocal window)."""
+    from graph_framework_amd.xrays import Rk4ColdPlasmaEfit, cli_distribution
+    n = 4096
+    rays = {k: np.ascontiguousarray(v[:n]) for k, v in cli_distribution(200000, seed=0).items()}
+    solve = Rk4ColdPlasmaEfit({k: v.copy() for k, v in rays.items()})
+    solve.init("kx", per_ray=True)
+    solve.compile()
+    cols = [rays[k].copy() for k in STATE]
+    loss = _oracle("loss_kernel_kx_f64.gfir")
+    for i in range(n):                                   # the converge loop on each ray alone
+        single = [c[i:i + 1].copy() for c in cols]
+        loss.converge(single)
+        for c, s in zip(cols, single):
+            c[i] = s[0]
+    assert np.array_equal(solve.sync_host()["kx"], cols[5])
+    item = _oracle("solver_kernel_f64.gfir")
+    flagged_at = None
+    for chunk in range(5):
+        item.run(cols, steps=100, threads=8)
+        solve.step(100)                                  # fused launch: same bits as 100 launches
+        host = solve.sync_host()
+        for k, expected in zip(STATE, cols):
+            assert np.array_equal(host[k], expected, equal_nan=True), (chunk, k)
+        if flagged_at is None and solve.work.context.flags():
+            flagged_at = chunk
+    lost = ~np.isfinite(cols[2])
+    assert 0 < lost.sum() < n//100                       # the reference graph loses a few rays of this beam
+    assert flagged_at is not None
