@@ -56,6 +56,9 @@ inline item reorder(const item &in, const std::vector<uint32_t> &order) {
 
 inline item schedule_for_pressure(const item &in) {
     const size_t n = in.code.size();
+//  The list schedule below is O(nodes x ready set); items far larger than anything on the path
+//  (the RK4 item has 3.9 k nodes) keep their own order rather than stall the lowering.
+    if (n > 20000) return in;
     std::vector<std::vector<uint32_t>> users(n);
     std::vector<uint32_t> pending(n, 0), consumers_left(n, 0);
     std::vector<bool> is_root(n, false);
