@@ -20,9 +20,11 @@ def build_library(force=False):
     csrc = os.path.join(_lib.HERE, "csrc")
     sources = glob.glob(os.path.join(csrc, "*")) + glob.glob(os.path.join(_lib.HERE, "..", "include", "*.h"))
     newest = max(os.path.getmtime(s) for s in sources)
-    bench = os.path.join(_lib.HERE, "xrays_bench")
+    programs = [os.path.join(_lib.HERE, name) for name in ("xrays_bench", "solver_check")]
+    sources.append(os.path.join(_lib.HERE, "gf_workflow.hpp"))
+    newest = max(os.path.getmtime(s) for s in sources)
     if (force or not os.path.exists(_lib.LIB_PATH) or os.path.getmtime(_lib.LIB_PATH) < newest
-            or not os.path.exists(bench) or os.path.getmtime(bench) < newest):
+            or any(not os.path.exists(p) or os.path.getmtime(p) < newest for p in programs)):
         subprocess.check_call(["make", "-C", csrc, "-s", "HIPCC=" + HIPCC])
     return _lib.LIB_PATH
 

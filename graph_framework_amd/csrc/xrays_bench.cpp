@@ -1,6 +1,7 @@
 //------------------------------------------------------------------------------
 ///  @file xrays_bench.cpp
-///  @brief Counterpart of graph_benchmark/xrays_bench.cpp on the C ABI of gf_hip.h.
+///  @brief Counterpart of graph_benchmark/xrays_bench.cpp on the C++ host mirror
+///  (graph_framework_amd/gf_workflow.hpp) of the reference's solver interface.
 ///
 ///  Same structure as the reference benchmark (xrays_bench.cpp:20-116): one host
 ///  thread per device (gfhip_max_concurrency(), jit.hpp:87), rays split into
@@ -9,11 +10,10 @@
 ///  :89), compile (:92), NUM_TIMES steps (:96-100), sync_host (:101), and the
 ///  four timers printed as averages over threads (timing.hpp:115-123).
 ///
-///  The two work items come from GFIR files (the DAGs the reference front end
-///  builds for this case); everything else goes through the C ABI, so this
-///  program needs neither the reference headers nor Python.
+///  The work items come from GFIR files (the DAGs the reference front end builds
+///  for this case); this program needs neither the reference headers nor Python.
 ///
-///  Usage: xrays_bench <loss_kernel.gfir> <solver_kernel.gfir> [num_rays=100000] [num_times=1000]
+///  Usage: xrays_bench <workload directory> [num_rays=100000] [num_times=1000]
 //------------------------------------------------------------------------------
 #include <algorithm>
 #include <chrono>
@@ -25,18 +25,9 @@
 #include <thread>
 #include <vector>
 
-#include "../../include/gf_hip.h"
+#include "../gf_workflow.hpp"
 
 namespace {
-
-std::vector<char> read_file(const char *path) {
-    std::ifstream f(path, std::ios::binary);
-    if (!f) {
-        std::cerr << "cannot open " << path << std::endl;
-        exit(1);
-    }
-    return std::vector<char> ((std::istreambuf_iterator<char> (f)), std::istreambuf_iterator<char> ());
-}
 
 //  timing::measure_diagnostic_threaded (timing.hpp:67-150).
 struct threaded_timer {
@@ -55,24 +46,16 @@ struct threaded_timer {
     }
 };
 
-void check(gfhip_context *ctx, const int status, const char *what) {
-    if (status) {
-        std::cerr << what << ": " << gfhip_last_error(ctx) << std::endl;
-        exit(1);
-    }
-}
-
 }  // namespace
 
 int main(int argc, char **argv) {
-    if (argc < 3) {
-        std::cerr << "usage: xrays_bench <loss_kernel.gfir> <solver_kernel.gfir> [num_rays] [num_times]" << std::endl;
+    if (argc < 2) {
+        std::cerr << "usage: xrays_bench <workload directory> [num_rays] [num_times]" << std::endl;
         return 2;
     }
-    const std::vector<char> loss = read_file(argv[1]);
-    const std::vector<char> solver = read_file(argv[2]);
-    const size_t num_rays = argc > 3 ? strtoull(argv[3], nullptr, 10) : 100000;
-    const size_t num_times = argc > 4 ? strtoull(argv[4], nullptr, 10) : 1000;
+    const std::string directory = argv[1];
+    const size_t num_rays = argc > 2 ? strtoull(argv[2], nullptr, 10) : 100000;
+    const size_t num_times = argc > 3 ? strtoull(argv[3], nullptr, 10) : 1000;
 
     const size_t devices = static_cast<size_t> (std::max(gfhip_max_concurrency(), 0));
     if (devices == 0) {
@@ -95,51 +78,31 @@ int main(int argc, char **argv) {
         threads[i] = std::thread([&, i] () {
             time_setup.start_time(i);
             const size_t local_num_rays = batch + (extra > i ? 1 : 0);
-            const std::vector<double> t(local_num_rays, 0.0), w(local_num_rays, 500.0), x(local_num_rays, 2.5);
-            const std::vector<double> y(local_num_rays, 0.0), z(local_num_rays, 0.0), kx(local_num_rays, -600.0);
-            const std::vector<double> ky(local_num_rays, 0.0), kz(local_num_rays, 0.0);
-            gfhip_context *ctx = gfhip_create_context(static_cast<int> (i), nullptr);
-            if (!ctx) {
-                std::cerr << gfhip_last_error(nullptr) << std::endl;
-                exit(1);
-            }
+            gf::solver::ray_solver<double> solve(directory, "", local_num_rays, i);
+            solve.state["w"].assign(local_num_rays, 500.0);                 // xrays_bench.cpp:62-71
+            solve.state["x"].assign(local_num_rays, 2.5);
+            solve.state["kx"].assign(local_num_rays, -600.0);
             time_setup.end_time(i);
 
-//  Buffer keys: t w x y z kx ky kz (solver.hpp:304-313), then the two residual outputs.
-            const uint64_t keys[8] = {1, 2, 3, 4, 5, 6, 7, 8};
-            const void *initial[8] = {t.data(), w.data(), x.data(), y.data(), z.data(), kx.data(), ky.data(), kz.data()};
-            const uint64_t newton_residual = 9, step_residual = 10;
-
             time_init.start_time(i);
-            gfhip_kernel *newton = gfhip_add_kernel(ctx, loss.data(), loss.size(), local_num_rays);
-            if (!newton) check(ctx, 1, "gfhip_add_kernel(loss_kernel)");
-            check(ctx, gfhip_compile(ctx), "gfhip_compile");
-            check(ctx, gfhip_create_kernel_call(newton, keys, initial, &newton_residual), "gfhip_create_kernel_call");
-            double last_max;
-            check(ctx, gfhip_converge(newton, 1.0E-30, 1000, &iterations[i], &last_max), "gfhip_converge");
+            solve.init("kx");
+            iterations[i] = solve.newton_iterations;
             time_init.end_time(i);
 
             time_compile.start_time(i);
-            gfhip_kernel *step = gfhip_add_kernel(ctx, solver.data(), solver.size(), local_num_rays);
-            if (!step) check(ctx, 1, "gfhip_add_kernel(solver_kernel)");
-            check(ctx, gfhip_compile(ctx), "gfhip_compile");
-            check(ctx, gfhip_create_kernel_call(step, keys, nullptr, &step_residual), "gfhip_create_kernel_call");
+            solve.compile();
             time_compile.end_time(i);
 
             time_steps.start_time(i);
             for (size_t j = 0; j < num_times; j++) {
-                check(ctx, gfhip_run(step, 1), "gfhip_run");
+                solve.step();
             }
-            std::vector<std::vector<double>> host(8, std::vector<double> (local_num_rays));
-            for (size_t k = 0; k < 8; k++) {                        // solve.sync_host(), solver.hpp:368-377
-                check(ctx, gfhip_copy_to_host(ctx, keys[k], host[k].data()), "gfhip_copy_to_host");
-            }
+            solve.sync_host();
             time_steps.end_time(i);
 
-            final_x[i] = host[2][local_num_rays - 1];
-            final_kx[i] = host[5][local_num_rays - 1];
-            check(ctx, gfhip_check_value(ctx, step_residual, 0, &residual[i]), "gfhip_check_value");
-            gfhip_destroy_context(ctx);
+            final_x[i] = solve.state["x"][local_num_rays - 1];
+            final_kx[i] = solve.state["kx"][local_num_rays - 1];
+            residual[i] = solve.check_residual(0);
         });
     }
     for (std::thread &t : threads) {

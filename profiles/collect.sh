@@ -19,4 +19,4 @@ for item in korc_f32 korc_f64 loss loss_per_ray fused solver_f32 stream_f32 stre
     python3 $R/bench_extra.py $item >> $OUT/${TAG}_extra_items.jsonl 2>> $OUT/${TAG}_extra.err || exit 1
 done
 python3 $R/bench.py --distribution cli --rays-per-gpu 10000000 --steps 50 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_bench_cli_1e7.json 2>> $OUT/${TAG}_extra.err || exit 1
-$R/graph_framework_amd/xrays_bench $R/graph_framework_amd/workloads/loss_kernel_kx_f64.gfir $R/graph_framework_amd/workloads/solver_kernel_f64.gfir 1000000 1000 > $OUT/${TAG}_xrays_bench_cpp.log 2>&1
+$R/graph_framework_amd/xrays_bench $R/graph_framework_amd/workloads 1000000 1000 > $OUT/${TAG}_xrays_bench_cpp.log 2>&1

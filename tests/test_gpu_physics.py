@@ -97,3 +97,25 @@ def test_reference_test_scenarios_on_the_gpu(physics_golden, name, scenario):
     result = scenario(GpuSolver)
     physics_scenarios.compare(result, physics_golden[name], exact=not physics_scenarios.uses_exp(name))
     assert result["holds"]
+
+
+@pytest.mark.parametrize("label,method,omega0,kx0,dt", physics_scenarios.SOLVER_TESTS,
+                         ids=["%s_%s" % (t[0], t[1]) for t in physics_scenarios.SOLVER_TESTS])
+def test_solver_test_on_the_cpp_host_mirror(physics_golden, label, method, omega0, kx0, dt):
+    """graph_tests/solver_test.cpp:28-60 through the C++ host side (graph_framework_amd/
+    gf_workflow.hpp: gf::workflow::manager, gf::solver::ray_solver; program csrc/solver_check.cpp)."""
+    import subprocess
+    from conftest import ROOT, WORKLOADS
+    binary = os.path.join(ROOT, "graph_framework_amd", "solver_check")
+    if not os.path.exists(binary):
+        pytest.skip("solver_check not built")
+    name = "solver_test_%s_%s" % (label, method)
+    out = subprocess.run([binary, WORKLOADS, "physics_%s_" % name, repr(omega0), repr(kx0), "0.25", "0.15", "5"],
+                         check=True, capture_output=True, text=True, timeout=300).stdout.splitlines()
+    golden = physics_golden[name]
+    assert out[0] == "newton_iterations %d" % golden["newton_iterations"][0]
+    states = [[float(v) for v in line.split()] for line in out[1:-1]]
+    result = {"states": [[row] for row in states], "newton_iterations": golden["newton_iterations"],
+              "holds": out[-1] == "holds 1"}
+    physics_scenarios.compare(result, golden, exact=not physics_scenarios.uses_exp(name))
+    assert result["holds"]
