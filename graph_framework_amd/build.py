@@ -20,7 +20,7 @@ def build_library(force=False):
     csrc = os.path.join(_lib.HERE, "csrc")
     sources = glob.glob(os.path.join(csrc, "*")) + glob.glob(os.path.join(_lib.HERE, "..", "include", "*.h"))
     newest = max(os.path.getmtime(s) for s in sources)
-    programs = [os.path.join(_lib.HERE, name) for name in ("xrays_bench", "solver_check")]
+    programs = [os.path.join(_lib.HERE, name) for name in ("xrays_bench", "solver_check", "korc_push")]
     sources.append(os.path.join(_lib.HERE, "gf_workflow.hpp"))
     newest = max(os.path.getmtime(s) for s in sources)
     if (force or not os.path.exists(_lib.LIB_PATH) or os.path.getmtime(_lib.LIB_PATH) < newest
