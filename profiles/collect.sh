@@ -14,6 +14,8 @@ for counters in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLE
     name=$(echo $counters | cut -d' ' -f1)
     rocprofv3 --pmc $counters --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$name -- python3 $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_pmc_$name.log 2>&1 || exit 1
 done
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_korc_f32 -- python3 $R/bench_extra.py korc_f32 > $OUT/${TAG}_prof_korc_f32.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_korc_f64 -- python3 $R/bench_extra.py korc_f64 > $OUT/${TAG}_prof_korc_f64.log 2>&1 || exit 1
 cd $R
 for item in korc_f32 korc_f64 loss loss_per_ray fused solver_f32 stream_f32 stream_f64 stream7_f32 stream7_f64 trajectory; do
     python3 $R/bench_extra.py $item >> $OUT/${TAG}_extra_items.jsonl 2>> $OUT/${TAG}_extra.err || exit 1
