@@ -1,34 +1,142 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: ray-steps/s of the xrays_bench cold-plasma RK4 `solver_kernel`.
 
-Workload (BASELINE.json configs[1]): graph_benchmark/xrays_bench.cpp:53-102 — every ray
-omega=500, x=2.5, kx=-600 -> Newton, dt=1e-3, cold_plasma on the EFIT equilibrium of
-graph_tests/efit.nc, fp64 — with 1e6 rays PER GPU (weak scaling).  A "step" is one launch of
-`solver_kernel` over the rank's rays (solver_interface::step, solver.hpp:382).  Setup, the
+Workload: graph_benchmark/xrays_bench.cpp:53-102 — every ray omega=500, x=2.5, kx=-600 -> Newton,
+dt=1e-3, cold_plasma on the EFIT equilibrium of graph_tests/efit.nc, fp64.  A "step" is one launch
+of `solver_kernel` over the rank's rays (solver_interface::step, solver.hpp:382).  Setup, the
 Newton init and kernel builds are outside the timed region, as in the reference
-(xrays_bench.cpp:88-102); inputs are resident in HBM when the timed region starts.  The
-reference's timed region also contains the final sync_host (8 D2H copies); that PCIe-inclusive
-rate is reported separately as "value_with_sync_host" and is never `value`.
+(xrays_bench.cpp:88-102); the state is resident in HBM when the timed region starts.
 
-    python bench.py --gpus N --steps K --warmup W          (N=1)
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N>1)
+Sizes:
+    --gpus 1  (default)  1e7 rays, the size BASELINE.json's north_star quotes its target on
+                         (--rays-per-gpu 1000000 is BASELINE configs[1]);
+    --gpus N > 1         one ensemble of 1e8 rays (BASELINE configs[3]) split over the ranks as the
+                         reference splits it over its device threads (xrays_bench.cpp:38-51):
+                         strong scaling.  --rays-per-gpu R selects weak scaling instead.
+
+Launch: one process per GPU.  Under torch.distributed.run (RANK/WORLD_SIZE in the environment) this
+process is one rank.  WITHOUT that environment `--gpus N` starts its own N rank processes — before
+anything here touches the GPU — collects rank 0's line and exits non-zero if any rank failed, like
+the reference's own benchmark, which needs no launcher (one thread per device,
+xrays_bench.cpp:34-108).
+
+`value` is the step-loop rate (K launches between barrier + synchronize on both sides).  The
+reference's timed region also holds the final sync_host (8 D2H copies, xrays_bench.cpp:95-102);
+that PCIe-inclusive rate of the same run is `value_with_sync_host`.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-
 BYTES_PER_RAY_STEP_F64 = 128      # read 8 + write 8 (7 setters + residual) x 8 B, SURVEY.md §8(d)
+BYTES_PER_RAY_ITERATION_F64 = 80  # loss_kernel: read 8 + write 2; the max is reduced inside the launch (no re-read)
+BYTES_PER_PARTICLE_STEP_F32 = 56  # xkorc step: (7 reads + 7 writes) x 4 B, SURVEY.md §8(d)
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+DEFAULT_RAYS_ONE_GPU = 10000000   # north_star: "1e7 cold-plasma rays at 1 MI355X"
+DEFAULT_TOTAL_RAYS = 100000000    # BASELINE configs[3]
+BENCH_RAY = dict(t=0.0, w=500.0, x=2.5, y=0.0, z=0.0, kx=-600.0, ky=0.0, kz=0.0)
 
 
+def parse_arguments(argv=None):
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--gpus", type=int, default=1)
+    parser.add_argument("--steps", type=int, default=200)
+    parser.add_argument("--warmup", type=int, default=10)
+    parser.add_argument("--rays-per-gpu", type=int, default=0,
+                        help="weak scaling: this many rays on every rank (default at --gpus 1: 1e7)")
+    parser.add_argument("--total-rays", type=int, default=0,
+                        help="strong scaling: one ensemble split over the ranks, xrays_bench.cpp:38-51 "
+                             "(default at --gpus N > 1: 1e8, BASELINE configs[3])")
+    parser.add_argument("--warmup-seconds", type=float, default=0.3,
+                        help="keep launching untimed steps after the --warmup steps until this much time has passed "
+                             "(the chip settles its clock under load over ~0.2 s)")
+    parser.add_argument("--no-cpu-baseline", action="store_true")
+    parser.add_argument("--no-extra", action="store_true",
+                        help="skip the secondary roofline objects (loss_kernel, xkorc step) and the weak-scaling leg")
+    parser.add_argument("--backend", choices=["nccl", "gloo"], default=None,
+                        help="torch.distributed backend (default nccl = RCCL); gloo + --share-gpu rehearses "
+                             "the multi-rank path on a one-GPU box")
+    parser.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses device 0")
+    parser.add_argument("--rehearse-cpu", action="store_true",
+                        help="no GPU: run only the multi-rank plumbing (rendezvous over gloo, item broadcast, shard "
+                             "split, all-gather, max-over-ranks) and print a rehearsal line; covered by tests/")
+    parser.add_argument("--fail-rank", type=int, default=-1, help="(rehearsal) this rank exits with an error")
+    parser.add_argument("--distribution", choices=["bench", "cli"], default="bench",
+                        help="bench: identical rays of xrays_bench.cpp:62-71 (the metric's workload); "
+                             "cli: the incoherent example distribution of graph_driver/xrays.cpp (BASELINE configs[2])")
+    return parser.parse_args(argv)
+
+
+# ----------------------------------------------------------------------------------------------
+#  Self-launch: N rank processes, started before any GPU call of this process.
+# ----------------------------------------------------------------------------------------------
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(world, argv, timeout=None):
+    """Start `world` copies of this script as ranks 0..world-1 (fresh processes, rendezvous on
+    127.0.0.1), wait for all of them, print rank 0's stdout.  Returns the exit code: non-zero
+    if any rank failed (the others are then stopped, by PID)."""
+    port = free_port()
+    procs, files = [], []
+    for rank in range(world):
+        env = dict(os.environ)
+        env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        out = tempfile.TemporaryFile(mode="w+")
+        files.append(out)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, stdout=out))
+    deadline = None if timeout is None else time.time() + timeout
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for rank, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = rank
+        if deadline is not None and time.time() > deadline:
+            failed = -1
+        time.sleep(0.1)
+    if failed is None:
+        for rank, p in enumerate(procs):
+            if p.returncode != 0:
+                failed = rank
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        sys.stderr.write("bench.py: rank %s failed (exit codes %s)\n"
+                         % ("timeout" if failed < 0 else failed, [p.returncode for p in procs]))
+#  Rank 0's result line goes to stdout; anything else a library wrote there (gloo announces its
+#  connections on stdout) goes to stderr, so that stdout stays ONE JSON line.
+    files[0].seek(0)
+    for text in files[0].read().splitlines():
+        (sys.stdout if text.startswith("{") else sys.stderr).write(text + "\n")
+    sys.stdout.flush()
+    for f in files:
+        f.close()
+    return 0 if failed is None else 1
+
+
+# ----------------------------------------------------------------------------------------------
+#  Helpers of one rank.
+# ----------------------------------------------------------------------------------------------
 def available_cores():
     """Host threads this process may actually use: the affinity mask, capped by the cgroup CPU
     quota when there is one (a container can see 256 CPUs and own 16)."""
@@ -73,18 +181,31 @@ def dag_flops(path):
     return flops
 
 
-def measured_traffic(kernel_name, rays):
-    """HBM bytes per launch from the committed PMC passes (profiles/r01_traffic.json: rocprofv3
-    --pmc FETCH_SIZE / WRITE_SIZE run on this same command), if they are for this launch size."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+def measured_traffic(kernel_name, source_hash, rays):
+    """HBM bytes per launch from the committed PMC passes (profiles/traffic.json, written by
+    profiles/summarize.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this command) —
+    only if they were taken for THIS code object (source hash) and launch size; else None."""
     try:
-        with open(path) as f:
-            entry = json.load(f).get(kernel_name)
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            entries = json.load(f)
     except (OSError, ValueError):
         return None
-    if entry and entry.get("rays_per_launch") == rays:
-        return entry["traffic_bytes_per_launch"]
+    for entry in entries if isinstance(entries, list) else []:
+        if (entry.get("kernel") == kernel_name and entry.get("source_hash") == "%016x" % source_hash
+                and entry.get("rays_per_launch") == rays):
+            return entry.get("traffic_bytes_per_launch")
     return None
+
+
+def sample_statistics(samples):
+    """Spread of the per-launch HIP-event durations (ms) over the timed region, first quarter
+    against last quarter included: a clock that is still settling shows up as a trend."""
+    if not samples:
+        return None
+    ordered = sorted(samples)
+    quarter = max(1, len(samples)//4)
+    return {"min": ordered[0], "median": ordered[len(ordered)//2], "max": ordered[-1],
+            "first_quarter_mean": sum(samples[:quarter])/quarter, "last_quarter_mean": sum(samples[-quarter:])/quarter}
 
 
 def cpu_baseline(target_seconds=12.0):
@@ -92,12 +213,12 @@ def cpu_baseline(target_seconds=12.0):
     the reference's cpu_context runs it (one compiled statement per node, serial loop per
     thread, contiguous shards; oracle/gfir_to_c.py, gcc -O2, strict IEEE), one thread per
     available core.  Falls back to the interpreter (oracle/gfir_interp.c) without gcc."""
+    import numpy as np
     from oracle import gfir
     from graph_framework_amd.xrays import STATE, workload
     cores = available_cores()
-    state = dict(t=0.0, w=500.0, x=2.5, y=0.0, z=0.0, kx=-600.0, ky=0.0, kz=0.0)
     rays = 256*cores
-    columns = [np.full(rays, state[k]) for k in STATE]
+    columns = [np.full(rays, BENCH_RAY[k]) for k in STATE]
     gfir.Item(workload("loss_kernel_kx")).converge(columns)
     how = "compiled by gcc from the DAG (oracle/gfir_to_c.py)"
     try:
@@ -118,44 +239,107 @@ def cpu_baseline(target_seconds=12.0):
     return rays*steps/seconds, cores, sample
 
 
-def main():
-    parser = argparse.ArgumentParser()
-    parser.add_argument("--gpus", type=int, default=1)
-    parser.add_argument("--steps", type=int, default=200)
-    parser.add_argument("--warmup", type=int, default=10)
-    parser.add_argument("--rays-per-gpu", type=int, default=1000000)
-    parser.add_argument("--total-rays", type=int, default=0,
-                        help="strong scaling (BASELINE configs[3]): a fixed ensemble split over the ranks as the "
-                             "reference splits it over device threads (xrays_bench.cpp:38-51); overrides --rays-per-gpu")
-    parser.add_argument("--no-cpu-baseline", action="store_true")
-    parser.add_argument("--backend", choices=["nccl", "gloo"], default=None,
-                        help="torch.distributed backend (default nccl = RCCL); gloo + --share-gpu rehearses "
-                             "the multi-rank path on a one-GPU box")
-    parser.add_argument("--share-gpu", action="store_true",
-                        help="rehearsal only: every rank uses device 0")
-    parser.add_argument("--distribution", choices=["bench", "cli"], default="bench",
-                        help="bench: identical rays of xrays_bench.cpp:62-71 (default, the metric's workload); "
-                             "cli: the incoherent example distribution of graph_driver/xrays.cpp (BASELINE configs[2])")
-    args = parser.parse_args()
+def hbm_roofline(kernel, units, bytes_per_unit, note=None):
+    """roofline object of one kernel from its HIP-event launch durations (gfhip_kernel_timing)."""
+    ms, launches = kernel.timing()
+    info = kernel.info()
+    achieved = units*bytes_per_unit/(ms*1.0e-3)/1.0e9 if ms > 0 else 0.0
+    name = info.name.decode()
+    out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved/HBM_PEAK_GBPS,
+           "traffic": measured_traffic(name, info.source_hash, units),
+           "kernel": name, "kernel_ms": ms, "launches": int(launches), "units_per_launch": units,
+           "algorithmic_bytes_per_launch": units*bytes_per_unit, "source_hash": "%016x" % info.source_hash}
+    if note:
+        out["note"] = note
+    return out
 
+
+def extra_rooflines(n_loss, newton_roofline):
+    """Secondary kernels of the path at BASELINE.json's sizes, outside the timed region: the
+    Newton `loss_kernel` (measured during this run's init) and the xkorc fp32 push, 1e7 particles."""
+    import numpy as np
+    from graph_framework_amd import korc as gk
+    extras = {"loss_kernel": newton_roofline}
+    n = 10000000
+    push = gk.Korc(dict(x=1.7, y=0.0, z=0.0, ux=0.0, uy=0.99, uz=0.1, gamma=np.zeros(n)), "f32")
+    push.compile()
+    push.pre_run()
+    for _ in range(20):
+        push.run()
+    push.wait()
+    push.work.context.enable_timing(True, every=4)
+    start = time.perf_counter()
+    steps = 200
+    for _ in range(steps):
+        push.run()
+    push.wait()
+    elapsed = time.perf_counter() - start
+    roof = hbm_roofline(push.step_item.kernel, n, BYTES_PER_PARTICLE_STEP_F32)
+    roof["value"] = n*steps/elapsed
+    roof["value_unit"] = "particle-steps/s"
+    roof["workload"] = "xkorc step fp32, 1e7 particles on one GPU (BASELINE configs[4] per-GPU kernel)"
+    extras["korc_step_f32"] = roof
+    push.work.context.close()
+    return extras
+
+
+def rehearse_cpu(args):
+    """The rank-side plumbing of run_rank without a device: what tests/test_distributed.py drives
+    through the self-launcher (and through torch.distributed.run) on a CPU-only host."""
+    import torch
+    from graph_framework_amd import distributed as gfd
+    from graph_framework_amd.xrays import STATE, shard_bounds, workload
+    rank, world, _ = gfd.init("gloo")
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if rank == args.fail_rank:
+        raise SystemExit("rank %d fails on request" % rank)
+    total = args.total_rays or (args.rays_per_gpu*world if args.rays_per_gpu else 1003)
+    begin, end = shard_bounds(total, world, rank)
+    data = b""
+    if rank == 0:
+        with open(workload("loss_kernel_kx"), "rb") as f:
+            data = f.read()
+    item = gfd.broadcast_bytes(data, 0)
+    gathered = 0
+    for k in range(len(STATE)):
+        full = gfd.all_gather_shards(torch.arange(begin, end, dtype=torch.float64) + k, total)
+        assert torch.equal(full, torch.arange(total, dtype=torch.float64) + k)
+        gathered += full.numel()
+    slowest = gfd.max_over_ranks(float(rank))
+    gfd.barrier()
+    if rank == 0:
+        print(json.dumps({"rehearsal": "cpu", "n_gpus": world, "total_rays": total, "item_bytes": len(item),
+                          "gathered_elements": gathered, "slowest_rank": slowest,
+                          "launcher": os.environ.get("GF_BENCH_LAUNCHER", "torchrun")}))
+        sys.stdout.flush()
+
+
+def run_rank(args):
+    import numpy as np
     import torch
     from graph_framework_amd import distributed as gfd
     from graph_framework_amd.xrays import Rk4ColdPlasmaEfit, STATE, shard_bounds, workload
 
     rank, world, local_rank = gfd.init(args.backend, device_index=0 if args.share_gpu else None)
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
 
-    if args.total_rays > 0:
-        begin, end = shard_bounds(args.total_rays, world, rank)
-        n_local = end - begin
-        total = args.total_rays
+    rays_per_gpu, total_rays = args.rays_per_gpu, args.total_rays
+    if not rays_per_gpu and not total_rays:
+        if world == 1:
+            rays_per_gpu = DEFAULT_RAYS_ONE_GPU
+        else:
+            total_rays = DEFAULT_TOTAL_RAYS
+    strong = total_rays > 0
+    if strong:
+        begin, end = shard_bounds(total_rays, world, rank)
+        n_local, total = end - begin, total_rays
     else:
-        n_local = args.rays_per_gpu
-        total = n_local*world
+        n_local, total = rays_per_gpu, rays_per_gpu*world
 
 #  Rank 0 reads the work items (they carry the equilibrium tables); RCCL broadcast to the rest.
     items = {}
@@ -166,19 +350,36 @@ def main():
                 data = f.read()
         items[name] = gfd.broadcast_bytes(data, 0)
 
-    if args.distribution == "bench":
-        state = dict(t=0.0, w=500.0, x=2.5, y=0.0, z=0.0, kx=-600.0, ky=0.0, kz=0.0)
-        initial = {k: np.full(n_local, v) for k, v in state.items()}
-    else:
-        from graph_framework_amd.xrays import cli_distribution
-        initial = cli_distribution(n_local, seed=rank)
-    solve = Rk4ColdPlasmaEfit(initial, index=local_rank, stream=torch.cuda.current_stream().cuda_stream,
-                              items=items)
-    solve.init("kx")
-    solve.compile()
+    def make_solver(count, seed):
+        if args.distribution == "bench":
+            initial = {k: np.full(count, v) for k, v in BENCH_RAY.items()}
+        else:
+            from graph_framework_amd.xrays import cli_distribution
+            initial = cli_distribution(count, seed=seed)
+#  The state lives in torch CUDA tensors adopted by the context (device_state): the output-cadence
+#  all-gather below reads them in place.
+        solver = Rk4ColdPlasmaEfit(initial, index=local_rank, items=items, device_state=True)
+        solver.work.context.enable_timing(True, every=1)
+        solver.init("kx")
+        solver.compile()
+        return solver
 
+    solve = make_solver(n_local, rank)
+    newton_roofline = hbm_roofline(solve.newton.kernel, n_local, BYTES_PER_RAY_ITERATION_F64,
+                                   note="Newton init of this run: one launch per iteration, max reduced in the launch")
+    solve.work.context.enable_timing(False)
+
+    warm_start = time.perf_counter()
+    warm_steps = 0
     for _ in range(args.warmup):
         solve.step()
+        warm_steps += 1
+    torch.cuda.synchronize()
+    while time.perf_counter() - warm_start < args.warmup_seconds:
+        for _ in range(10):
+            solve.step()
+        warm_steps += 10
+        torch.cuda.synchronize()
 #  HIP events on the launch stream around every 8th step of the timed region (an event pair
 #  costs the stream 2-8 us; around every launch they would slow the loop they measure by 1-3 %).
     timing_period = 8 if args.steps >= 64 else 1
@@ -193,74 +394,137 @@ def main():
     gfd.barrier()
     elapsed = time.perf_counter() - start
     sync_start = time.perf_counter()
-    host = solve.sync_host()
+    solve.sync_host()
     sync_elapsed = time.perf_counter() - sync_start
 
     elapsed = gfd.max_over_ranks(elapsed)
     sync_elapsed = gfd.max_over_ranks(sync_elapsed)
-    kernel_ms, launches = solve.solver.kernel.timing()
+    samples = solve.solver.kernel.timing_samples()
+    kernel_ms = sum(samples)/len(samples) if samples else 0.0
+    launches = len(samples)
     kernel_ms = gfd.max_over_ranks(kernel_ms)
+    solve.work.context.enable_timing(False)
 
-#  Output-cadence collective: all-gather of the trajectory state over xGMI (not in the step loop).
+#  Output-cadence collective: all-gather of the trajectory state over xGMI, from the device
+#  tensors the kernels write (not in the step loop; gloo rehearsals gather host copies).
     gather_seconds = None
     if world > 1:
         on_device = torch.distributed.get_backend() == "nccl"
-        shards = {k: (torch.from_numpy(host[k]).cuda() if on_device else torch.from_numpy(host[k])) for k in STATE}
         torch.cuda.synchronize()
+        gfd.barrier()
         t0 = time.perf_counter()
         for k in STATE:
-            full = gfd.all_gather_shards(shards[k], total)
+            shard = solve.device[k] if on_device else solve.device[k].cpu()
+            full = gfd.all_gather_shards(shard, total)
             assert full.numel() == total
+            del full
         torch.cuda.synchronize()
         gather_seconds = gfd.max_over_ranks(time.perf_counter() - t0)
 
-    if rank == 0:
-        info = solve.solver.kernel.info()
-        value = total*args.steps/elapsed
-        flops = dag_flops(workload("solver_kernel"))
-        achieved = n_local*BYTES_PER_RAY_STEP_F64/(kernel_ms*1.0e-3)/1.0e9 if kernel_ms > 0 else 0.0
-        line = {
-            "metric": "ray-steps/sec on xrays_bench cold-plasma; achieved HBM GB/s vs peak",
-            "value": value,
-            "unit": "ray-steps/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": 1.0e3*elapsed/args.steps,
-            "higher_is_better": True,
-            "scaling": "strong" if args.total_rays > 0 else "weak",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": ("xrays_bench cold-plasma RK4 solver_kernel on EFIT (efit.nc), identical rays "
-                                    "omega=500 x=2.5 kx=Newton(-600), dt=1e-3, fp64") if args.distribution == "bench" else
-                                   ("xrays cold-plasma RK4 solver_kernel on EFIT (efit.nc), incoherent CLI example "
-                                    "distribution, dt=1e-3, fp64"),
-                       "rays_per_gpu": n_local, "total_rays": total, "parallelism": "rays sharded x%d" % world,
-                       "kernel_nodes": int(info.num_instructions), "vgprs": int(info.vgprs),
-                       "lds_bytes": int(info.lds_bytes), "scratch_bytes": int(info.scratch_bytes),
-                       "code_object_from_cache": bool(info.from_cache)},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved/HBM_PEAK_GBPS, "traffic": measured_traffic(info.name.decode(), n_local),
-                         "kernel": info.name.decode(), "kernel_ms": kernel_ms, "launches": int(launches),
-                         "timed_every": timing_period,
-                         "algorithmic_bytes_per_launch": n_local*BYTES_PER_RAY_STEP_F64,
-                         "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r01_solver_kernel.md)",
-                         "note": "the kernel is FP64-VALU issue bound (6.4k vector instructions per ray-step, "
-                                 "VALU busy 86 % at one wave per SIMD), not HBM bound: see DESIGN.md section 3"},
-            "fp64_vector": {"flops_per_ray_step": flops, "achieved_tflops": value/world*flops/1.0e12,
-                            "peak_tflops": 78.6, "frac": value/world*flops/1.0e12/78.6,
-                            "note": "per GPU; reference-DAG operation count, the roof that binds this kernel"},
-            "value_with_sync_host": total*args.steps/(elapsed + sync_elapsed),
-            "newton_iterations": solve.newton_iterations,
-        }
-        if gather_seconds is not None:
-            line["all_gather_seconds"] = gather_seconds
-        if world == 1 and not args.no_cpu_baseline:
-            rate, cores, sample = cpu_baseline()
-            line["cpu_baseline"] = {"value": rate, "unit": "ray-steps/s", "cores": cores, "kind": "port",
-                                    "sample": sample}
-        print(json.dumps(line))
+#  Weak-scaling leg beside a strong-scaling run: the same loop at 1e7 rays on every rank.
+    weak = None
+    if strong and world > 1 and not args.no_extra:
+        weak_rays, weak_steps = DEFAULT_RAYS_ONE_GPU, 50
+        other = make_solver(weak_rays, rank)
+        other.work.context.enable_timing(False)
+        for _ in range(10):
+            other.step()
+        gfd.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(weak_steps):
+            other.step()
+        torch.cuda.synchronize()
+        gfd.barrier()
+        weak_elapsed = gfd.max_over_ranks(time.perf_counter() - t0)
+        weak = {"scaling": "weak", "rays_per_gpu": weak_rays, "steps": weak_steps,
+                "value": weak_rays*world*weak_steps/weak_elapsed, "unit": "ray-steps/s"}
+        other.work.context.close()
+
+    if rank != 0:
+        return
+    info = solve.solver.kernel.info()
+    value = total*args.steps/elapsed
+    flops = dag_flops(workload("solver_kernel"))
+    name = info.name.decode()
+    achieved = n_local*BYTES_PER_RAY_STEP_F64/(kernel_ms*1.0e-3)/1.0e9 if kernel_ms > 0 else 0.0
+    distributed_info = {"world_size": world, "launcher": os.environ.get("GF_BENCH_LAUNCHER", "torchrun" if world > 1 else "none")}
+    if world > 1:
+        distributed_info["backend"] = torch.distributed.get_backend()
+        try:
+            distributed_info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            distributed_info["rccl_version"] = None
+    line = {
+        "metric": "ray-steps/sec on xrays_bench cold-plasma; achieved HBM GB/s vs peak",
+        "value": value,
+        "unit": "ray-steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1.0e3*elapsed/args.steps,
+        "higher_is_better": True,
+        "scaling": "strong" if strong else "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": ("xrays_bench cold-plasma RK4 solver_kernel on EFIT (efit.nc), identical rays "
+                                "omega=500 x=2.5 kx=Newton(-600), dt=1e-3, fp64") if args.distribution == "bench" else
+                               ("xrays cold-plasma RK4 solver_kernel on EFIT (efit.nc), incoherent CLI example "
+                                "distribution, dt=1e-3, fp64"),
+                   "rays_per_gpu": n_local, "total_rays": total, "parallelism": "rays sharded x%d" % world,
+                   "kernel_nodes": int(info.num_instructions), "vgprs": int(info.vgprs),
+                   "lds_bytes": int(info.lds_bytes), "scratch_bytes": int(info.scratch_bytes),
+                   "code_object_from_cache": bool(info.from_cache), "warmup_steps_run": warm_steps},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved/HBM_PEAK_GBPS, "traffic": measured_traffic(name, info.source_hash, n_local),
+                     "kernel": name, "kernel_ms": kernel_ms, "launches": int(launches),
+                     "timed_every": timing_period, "kernel_ms_samples": sample_statistics(samples),
+                     "algorithmic_bytes_per_launch": n_local*BYTES_PER_RAY_STEP_F64,
+                     "source_hash": "%016x" % info.source_hash,
+                     "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE of profiles/traffic.json), null "
+                                     "unless measured for this source hash and launch size",
+                     "note": "the kernel is FP64-VALU issue bound (one wave per SIMD, 4 cycles per vector "
+                             "instruction), not HBM bound: see DESIGN.md section 3"},
+        "fp64_vector": {"flops_per_ray_step": flops, "achieved_tflops": value/world*flops/1.0e12,
+                        "peak_tflops": 78.6, "frac": value/world*flops/1.0e12/78.6,
+                        "note": "per GPU; reference-DAG operation count, the roof that binds this kernel"},
+        "value_with_sync_host": total*args.steps/(elapsed + sync_elapsed),
+        "sync_host_seconds": sync_elapsed,
+        "newton_iterations": solve.newton_iterations,
+        "distributed": distributed_info,
+    }
+    if gather_seconds is not None:
+        line["all_gather_seconds"] = gather_seconds
+        line["all_gather_bytes"] = total*8*len(STATE)
+    if weak is not None:
+        line["weak_scaling"] = weak
+    if world == 1 and not args.no_extra:
+        line["roofline_extra"] = extra_rooflines(n_local, newton_roofline)
+    if world == 1 and not args.no_cpu_baseline:
+        rate, cores, sample = cpu_baseline()
+        line["cpu_baseline"] = {"value": rate, "unit": "ray-steps/s", "cores": cores, "kind": "port",
+                                "sample": sample}
+    print(json.dumps(line))
+    sys.stdout.flush()
+
+
+def main():
+    args = parse_arguments()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+#  No launcher around us: become the launcher.  Nothing above has imported torch or touched HIP.
+        os.environ["GF_BENCH_LAUNCHER"] = "bench.py"
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.rehearse_cpu:
+        rehearse_cpu(args)
+    else:
+        run_rank(args)
+    try:
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.destroy_process_group()
+    except Exception:
+        pass
 
 
 if __name__ == "__main__":

@@ -38,7 +38,7 @@ SYMBOLS = [
     ("gfhip_last_error", ctypes.c_char_p, [_P]),
     ("gfhip_add_kernel", _P, [_P, _P, _S, _S]),
     ("gfhip_compile", _I, [_P]),
-    ("gfhip_create_kernel_call", _I, [_P, _P, _P, _P]),
+    ("gfhip_create_kernel_call", _I, [_P, _P, _P, _P, _P]),
     ("gfhip_run", _I, [_P, _U32]),
     ("gfhip_run_max", _I, [_P, ctypes.POINTER(ctypes.c_double)]),
     ("gfhip_converge", _I, [_P, ctypes.c_double, _S, ctypes.POINTER(_S), ctypes.POINTER(ctypes.c_double)]),
@@ -49,12 +49,16 @@ SYMBOLS = [
     ("gfhip_copy_to_host", _I, [_P, _U64, _P]),
     ("gfhip_check_value", _I, [_P, _U64, _S, ctypes.POINTER(ctypes.c_double)]),
     ("gfhip_get_buffer", _P, [_P, _U64, ctypes.POINTER(_S)]),
+    ("gfhip_allocate_buffer", _I, [_P, _U64, _S, _U32]),
+    ("gfhip_get_buffer_info", _I, [_P, _U64, ctypes.POINTER(_S), ctypes.POINTER(_U32)]),
+    ("gfhip_get_host_buffer", _P, [_P, _U64, ctypes.POINTER(_S)]),
     ("gfhip_set_buffer", _I, [_P, _U64, _P, _S, _U32]),
     ("gfhip_kernel_get_info", _I, [_P, ctypes.POINTER(KernelInfo)]),
     ("gfhip_generate_source", _P, [_P, _S, ctypes.POINTER(_U64)]),
     ("gfhip_free_string", None, [_P]),
     ("gfhip_enable_timing", _I, [_P, _I]),
     ("gfhip_kernel_timing", _I, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_U64)]),
+    ("gfhip_kernel_timing_samples", _I, [_P, ctypes.POINTER(ctypes.c_double), _S, ctypes.POINTER(_S)]),
 ]
 
 _lib = None

@@ -88,14 +88,41 @@ class Context:
         self._check(self.lib.gfhip_get_flags(self.handle, ctypes.byref(value)))
         return value.value
 
+    def buffer_info(self, key):
+        """(element count, numpy dtype) of a buffer."""
+        count, dtype = ctypes.c_size_t(), ctypes.c_uint32()
+        self._check(self.lib.gfhip_get_buffer_info(self.handle, key_of(key), ctypes.byref(count), ctypes.byref(dtype)))
+        return count.value, _NP[dtype.value]
+
     def copy_to_device(self, key, host):
-        host = np.ascontiguousarray(host)
+        """Whole-buffer H2D copy (jit.hpp:315-320).  The C side copies the buffer's own size,
+        so the host array is converted to the buffer's dtype and must hold that many elements."""
+        count, dtype = self.buffer_info(key)
+        host = np.ascontiguousarray(host, dtype=dtype)
+        if host.size < count:
+            raise ValueError("copy_to_device(%r): %d host elements for a buffer of %d" % (key, host.size, count))
         self._check(self.lib.gfhip_copy_to_device(self.handle, key_of(key), host.ctypes.data))
 
     def copy_to_host(self, key, host):
-        assert host.flags["C_CONTIGUOUS"]
+        """Whole-buffer D2H copy (jit.hpp:324-329) into `host`: a C-contiguous numpy array of the
+        buffer's dtype with room for the whole buffer."""
+        count, dtype = self.buffer_info(key)
+        if not isinstance(host, np.ndarray) or host.dtype != dtype or not host.flags["C_CONTIGUOUS"] or host.size < count:
+            raise ValueError("copy_to_host(%r): need a contiguous %s array of at least %d elements"
+                             % (key, np.dtype(dtype).name, count))
         self._check(self.lib.gfhip_copy_to_host(self.handle, key_of(key), host.ctypes.data))
         return host
+
+    def get_host_buffer(self, key):
+        """jit::context::get_buffer (jit.hpp:336): a pinned host mirror of the buffer as a numpy
+        view, refreshed by every wait()."""
+        count = ctypes.c_size_t()
+        pointer = self.lib.gfhip_get_host_buffer(self.handle, key_of(key), ctypes.byref(count))
+        if not pointer:
+            raise GfHipError(self.lib.gfhip_last_error(self.handle).decode())
+        _, dtype = self.buffer_info(key)
+        ctype = ctypes.c_double if dtype is np.float64 else ctypes.c_float
+        return np.ctypeslib.as_array(ctypes.cast(pointer, ctypes.POINTER(ctype)), shape=(count.value,))
 
     def check_value(self, index, key):
         value = ctypes.c_double()
@@ -147,15 +174,18 @@ class Kernel:
         in_keys = (ctypes.c_uint64*max(len(input_keys), 1))(*[key_of(k) for k in input_keys])
         out_keys = (ctypes.c_uint64*max(len(output_keys), 1))(*[key_of(k) for k in output_keys])
         init = (ctypes.c_void_p*max(len(input_keys), 1))()
+        counts = (ctypes.c_size_t*max(len(input_keys), 1))()
         keep = []
         for i, key in enumerate(input_keys):
             value = None if input_init is None else input_init[i]
             if value is not None:
                 value = np.ascontiguousarray(value, dtype=_NP[info.dtype])
-                assert value.size >= self.num_rays
+                if value.size < self.num_rays:
+                    raise ValueError("initial values of %r: %d elements for %d rays" % (key, value.size, self.num_rays))
                 keep.append(value)
                 init[i] = value.ctypes.data
-        self.context._check(self.lib.gfhip_create_kernel_call(self.handle, in_keys, init, out_keys))
+                counts[i] = self.num_rays
+        self.context._check(self.lib.gfhip_create_kernel_call(self.handle, in_keys, init, counts, out_keys))
 
     def run(self, steps=1):
         self.context._check(self.lib.gfhip_run(self.handle, int(steps)))
@@ -181,6 +211,14 @@ class Kernel:
         self.context._check(self.lib.gfhip_converge_per_ray(self.handle, float(tolerance), int(max_iterations),
                                                             ctypes.byref(iterations), ctypes.byref(last)))
         return iterations.value, last.value
+
+    def timing_samples(self):
+        """Durations (ms) of the sampled launches since the last timing call, in launch order."""
+        count = ctypes.c_size_t()
+        self.context._check(self.lib.gfhip_kernel_timing_samples(self.handle, None, 0, ctypes.byref(count)))
+        values = (ctypes.c_double*max(count.value, 1))()
+        self.context._check(self.lib.gfhip_kernel_timing_samples(self.handle, values, count.value, ctypes.byref(count)))
+        return [values[i] for i in range(count.value)]
 
     def timing(self):
         """(average launch ms, launches) since the last call; needs Context.enable_timing()."""

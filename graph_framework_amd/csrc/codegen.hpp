@@ -20,15 +20,19 @@
 ///    8 per RK4 step instead of 360 — and all tables of one shape are packed
 ///    AoS `[cell][table]`, so the 45 coefficients a lane needs at its cell sit
 ///    in consecutive bytes;
-///  * packs that fit the LDS budget (the 1-D profile tables: 138 bins x 45
-///    tables x 8 B = 50 KB) are staged into LDS once per workgroup; the 2-D
-///    psi pack (1.5 MB) stays L2 resident (4 MiB per XCD);
+///  * packs that fit the LDS budget (the 1-D profile tables) are staged into LDS
+///    once per workgroup; the 2-D psi pack stays L2 resident (4 MiB per XCD);
 ///  * `steps` passes can run inside one launch with the state kept in
-///    registers (the reference launches once per step, solver.hpp:382).
+///    registers (the reference launches once per step, solver.hpp:382);
+///  * small items with an output get two more entry points: `<name>_max` folds the
+///    max of the last output into the launch (wave shuffle + one atomic per
+///    workgroup) — what create_max_call needs, where cuda_context.hpp:540-576
+///    runs a second kernel over the output — and `<name>_converge` runs the stall
+///    loop of workflow.hpp:179-205 per ray inside the launch.
 ///
 ///  Pieces: options.hpp (knobs, cache hash), schedule.hpp (emission order),
 ///  tables.hpp (compaction, packs, LDS staging), parking.hpp (values that wait
-///  in LDS), prelude.hpp (device helpers: division, window check, pow), and
+///  in LDS), prelude.hpp (device helpers: division, window checks, pow), and
 ///  lower() below, which writes the kernel text.
 //------------------------------------------------------------------------------
 #ifndef gfhip_codegen_hpp
@@ -46,8 +50,6 @@
 #include <string>
 #include <tuple>
 #include <vector>
-
-#include <fstream>
 
 #include "gfir_item.hpp"
 #include "options.hpp"
@@ -68,14 +70,16 @@ struct lowered {
     uint32_t block_size = 256;
     size_t lds_bytes = 0;
     uint32_t park_slots = 0;            ///< LDS slots used for parked values
-    uint32_t elements = 1;              ///< consecutive rays owned by one lane
     bool has_converge = false;          ///< the module also holds `<name>_converge`
+    bool has_max = false;               ///< the module also holds `<name>_max`
     uint64_t hash = 0;
 };
 
+///  Entry points of one item's module.
+enum class entry { plain, max, converge };
+
 //------------------------------------------------------------------------------
-///  @brief Writes the kernel text of one lowered item (`<name>` and, for items
-///  that can converge per ray, `<name>_converge`).
+///  @brief Writes the kernel text of one lowered item.
 //------------------------------------------------------------------------------
 struct kernel_writer {
     std::ostringstream &s;
@@ -89,17 +93,15 @@ struct kernel_writer {
     const size_t lds_used;                          ///< staged packs + parking slots, bytes
     const size_t park_offset;
     const uint32_t park_slots;
-    const uint32_t E;                               ///< rays per lane
-    const bool packed;                              ///< ... held as one float2
-    const bool use_shared;                          ///< shared-reciprocal division
+    const bool use_shared;                          ///< shared-reciprocal division with the IEEE second body
+    const std::vector<bool> &after_division;        ///< node depends on the result of a division
 
     const bool f64 = it.dtype == GFIR_F64;
+    const bool track_numerators = opt.division == division_mode::checked;
     const char *real = f64 ? "double" : "float";
     const std::string sfx = f64 ? "" : "f";
     const size_t esize = it.element_size();
     const size_t node_count = it.code.size();
-    const std::string VT = packed ? "real2" : "real";         ///< type of a value of the pass
-    bool prefetch = false;                          ///< next-tile prefetch in the kernel being written
 
     std::string literal(const double v) const {
         char buf[64];
@@ -116,8 +118,8 @@ struct kernel_writer {
     }
 
 //  The node-for-node body.  `shared` = divisions through a reciprocal shared by all
-//  divisions with the same denominator (see gf_rcp/gf_div in the prelude); otherwise the
-//  compiler's IEEE division.
+//  divisions with the same denominator (gf_rcp/gf_div in the prelude) plus the checks that
+//  tell whether the lane may keep that result; otherwise the compiler's IEEE division.
     void body(const bool shared) {
         typedef std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, double, double, double, double> group_key;
         std::map<group_key, std::string> groups;
@@ -127,32 +129,25 @@ struct kernel_writer {
 //  Current name of every value (changes when a parked value is reloaded).
         std::vector<std::string> name(node_count);
         for (size_t v = 0; v < node_count; v++) name[v] = "r" + std::to_string(v);
-        auto name_of = [&] (const uint32_t v) -> std::string { return name[v]; };
+        auto N = [&] (const uint32_t v) -> const std::string & { return name[v]; };
+//  Index of one dimension of a gather: clamp((x - offset)/scale) truncated (compile_index,
+//  piecewise.hpp:26-65).  The shared form divides through the correctly rounded literal
+//  1/scale (gf_div's residual step makes the quotient the correctly rounded one) and hands the
+//  quotient to the finite check: an overflowing or non-finite argument comes out of the shared
+//  sequence as a NaN, which clamps to cell 0 where IEEE division's infinity clamps to the last.
+        size_t quotient_count = 0;
         auto index_expression = [&] (const uint32_t arg, const double scale, const double offset,
                                      const uint32_t length) -> std::string {
             std::ostringstream e;
-            if (packed) {
-//  Clamped quotient as a float2; the caller converts each component.
-                const std::string zero = "(real2)(" + literal(0.0) + ")";
-                const std::string top = "(real2)(" + literal(static_cast<double> (length - 1)) + ")";
-                e << "__builtin_elementwise_min(__builtin_elementwise_max(";
-                if (shared) {
-                    e << "gf_div(" << name_of(arg) << " - (real2)(" << literal(offset) << "), (real2)(" << literal(scale)
-                      << "), (real2)(" << literal(static_cast<double> (1.0f/static_cast<float> (scale))) << "))";
-                } else {
-                    e << "(" << name_of(arg) << " - (real2)(" << literal(offset) << "))/(real2)(" << literal(scale) << ")";
-                }
-                e << ", " << zero << "), " << top << ")";
-                return e.str();
-            }
             e << "static_cast<unsigned int> (__builtin_fmin" << sfx << "(__builtin_fmax" << sfx << "(";
             if (shared) {
-//  The reciprocal literal is the correctly rounded 1/scale; gf_div's residual step makes
-//  the quotient the correctly rounded (r - offset)/scale.
-                e << "gf_div(" << name_of(arg) << " - " << literal(offset) << ", " << literal(scale) << ", "
-                  << literal(f64 ? 1.0/scale : static_cast<double> (1.0f/static_cast<float> (scale))) << ")";
+                const std::string quotient = "x" + std::to_string(quotient_count++);
+                s << "                const real " << quotient << " = gf_div(" << N(arg) << " - " << literal(offset) << ", " << literal(scale) << ", "
+                  << literal(f64 ? 1.0/scale : static_cast<double> (1.0f/static_cast<float> (scale))) << ");\n";
+                s << "                finite_check += " << quotient << ";\n";
+                e << quotient;
             } else {
-                e << "(" << name_of(arg) << " - " << literal(offset) << ")/" << literal(scale);
+                e << "(" << N(arg) << " - " << literal(offset) << ")/" << literal(scale);
             }
             e << ", " << literal(0.0) << "), " << literal(static_cast<double> (length - 1)) << "))";
             return e.str();
@@ -172,7 +167,6 @@ struct kernel_writer {
                 s << ind << "const real " << name[v] << " = park_read[" << plan[v].slot*out.block_size << "u];\n";
             }
         };
-        auto N = [&] (const uint32_t v) -> const std::string & { return name[v]; };
 //  Value of table `t` at the cell of index group `group`: a load for stored tables, an exact
 //  multiple of the parent's value otherwise; one definition per (group, table).
         std::function<std::string(const std::string &, uint32_t)> value_at =
@@ -181,16 +175,11 @@ struct kernel_writer {
             if (coefficients.insert(value_name).second) {
                 if (parent[t] >= 0) {
                     const std::string from = value_at(group, static_cast<uint32_t> (parent[t]));
-                    s << ind << "const " << VT << " " << value_name << " = " << literal(factor[t]) << "*" << from << ";\n";
+                    s << ind << "const real " << value_name << " = " << literal(factor[t]) << "*" << from << ";\n";
                 } else {
                     const uint32_t pi = table_pack[t];
                     const std::string base = (out.packs[pi].in_lds ? "lds" : "pack") + std::to_string(pi);
-                    if (packed) {
-                        s << ind << "const real2 " << value_name << " = {" << base << "[" << group << "_0 + " << table_column[t]
-                          << "u], " << base << "[" << group << "_1 + " << table_column[t] << "u]};\n";
-                    } else {
-                        s << ind << "const real " << value_name << " = " << base << "[" << group << " + " << table_column[t] << "u];\n";
-                    }
+                    s << ind << "const real " << value_name << " = " << base << "[" << group << " + " << table_column[t] << "u];\n";
                 }
             }
             return value_name;
@@ -200,140 +189,82 @@ struct kernel_writer {
             auto found = deferred.find(v);
             if (found == deferred.end()) return;
             const std::string value = value_at(found->second.first, found->second.second);
-            s << ind << "const " << VT << " r" << v << " = " << value << ";\n";
+            s << ind << "const real r" << v << " = " << value << ";\n";
             deferred.erase(found);
         };
-//  Next-tile prefetch: vmcnt retires in order, so a load issued before a gather makes the
-//  gather's wait last as long as the (HBM-latency) prefetch.  The prefetch goes after the last
-//  gather of the pass; the rest of the pass (>= ~20 % of it in the RK4 item) covers its latency.
-        size_t prefetch_position = 0;
-        {
-//  The latest gather that is followed by at least `prefetch_min_gap` gather-free nodes (the
-//  tail of the pass counts as a gap); failing that, the one followed by the widest gap.
-            std::vector<size_t> gathers;
-            for (size_t i = 0; i < it.code.size(); i++) {
-                if (it.code[i].op == GFIR_GATHER1 || it.code[i].op == GFIR_GATHER2) gathers.push_back(i);
-            }
-            size_t widest = 0;
-            bool satisfied = false;
-            for (size_t k = 0; k < gathers.size(); k++) {
-                const size_t next = k + 1 < gathers.size() ? gathers[k + 1] : it.code.size();
-                const size_t gap = next - gathers[k] - 1;
-                if (gap >= opt.prefetch_min_gap) {
-                    if (!(opt.pipeline_tiles && satisfied)) prefetch_position = gathers[k] + 1;
-                    satisfied = true;
-                } else if (!satisfied && gap > widest) {
-                    widest = gap;
-                    prefetch_position = gathers[k] + 1;
-                }
-            }
-        }
         for (size_t i = 0; i < it.code.size(); i++) {
             const gfir_instruction &c = it.code[i];
-            if (prefetch && i == prefetch_position) {
-//  Unconditional (a branch would split the scheduling region): passes before the last one of a
-//  fused launch, and the last tile, re-read this tile's own (cached) element.
-                s << ind << "unsigned long long ahead = (step + 1u == steps && g + stride < groups) ? g + stride : g;\n";
-                if (prefetch_position > 0) {
-                    define(static_cast<uint32_t> (prefetch_position - 1));
-//  Tie the address to the last gather's result, or the compiler hoists the loads to the top.
-                    s << ind << "asm volatile(\"\" : \"+v\"(ahead) : \"v\"(" << N(static_cast<uint32_t> (prefetch_position - 1)) << "));\n";
-                }
-                for (size_t k = 0; k < it.symbols.size(); k++) {
-                    s << ind << "next" << k << " = in" << k << "[ahead];\n";
-                }
-                if (opt.pipeline_tiles) {
-//  The previous tile's results leave here: a store issued at the end of a pass would still be
-//  in flight at the next pass's first gather wait (vmcnt retires stores and loads in order).
-                    s << ind << "if (step == 0u && have_pending) {\n";
-                    for (size_t k = 0; k < it.symbols.size(); k++) {
-                        if (out.input_written[k]) s << ind << "    in" << k << "[pending_index] = pending_v" << k << ";\n";
-                    }
-                    for (size_t o = 0; o < it.outputs.size(); o++) {
-                        s << ind << "    out" << o << "[pending_index] = pending_o" << o << ";\n";
-                    }
-                    s << ind << "    have_pending = false;\n";
-                    s << ind << "}\n";
-                }
-//  ... and keep the scheduler from sinking them to the end of the pass.
-                s << ind << "__builtin_amdgcn_sched_barrier(0);\n";
-            }
             reload(i);
             {
                 const uint32_t operands[3] = {c.a, c.b, c.c};
                 for (int k = 0; k < operand_count(c.op); k++) define(operands[k]);
             }
-            if ((opt.sched_barrier_every && i && i%opt.sched_barrier_every == 0) ||
-                std::find(it.fences.begin(), it.fences.end(), static_cast<uint32_t> (i)) != it.fences.end()) {
-                s << ind << "__builtin_amdgcn_sched_barrier(0);\n";
-            }
             switch (c.op) {
                 case GFIR_CONST:
-                    s << ind << "const " << VT << " r" << i << " = " << literal(c.imm[0]) << ";\n";
+                    s << ind << "const real r" << i << " = " << literal(c.imm[0]) << ";\n";
                     break;
                 case GFIR_INPUT:
-                    s << ind << "const " << VT << " r" << i << " = " << (packed ? "V" + std::to_string(c.a) : "v" + std::to_string(c.a) + "[e]") << ";\n";
+                    s << ind << "const real r" << i << " = v" << c.a << ";\n";
                     break;
                 case GFIR_ADD:
-                    s << ind << "const " << VT << " r" << i << " = " << N(c.a) << " + " << N(c.b) << ";\n";
+                    s << ind << "const real r" << i << " = " << N(c.a) << " + " << N(c.b) << ";\n";
                     break;
                 case GFIR_SUB:
-                    s << ind << "const " << VT << " r" << i << " = " << N(c.a) << " - " << N(c.b) << ";\n";
+                    s << ind << "const real r" << i << " = " << N(c.a) << " - " << N(c.b) << ";\n";
                     break;
                 case GFIR_MUL:
-                    s << ind << "const " << VT << " r" << i << " = " << N(c.a) << "*" << N(c.b) << ";\n";
+                    s << ind << "const real r" << i << " = " << N(c.a) << "*" << N(c.b) << ";\n";
                     break;
                 case GFIR_DIV:
                     if (shared) {
                         if (!reciprocal_done[c.b]) {
                             reciprocal_done[c.b] = true;
-                            s << ind << "const " << VT << " q" << c.b << " = gf_rcp(" << N(c.b) << ");\n";
-                            for (const char *member : {".x", ".y"}) {
-                                const std::string component = N(c.b) + (packed ? member : "");
-                                s << ind << "dmax = __builtin_elementwise_maximum(dmax, gf_magnitude(" << component << "));\n";
-                                s << ind << "dmin = __builtin_elementwise_minimum(dmin, gf_magnitude(" << component << "));\n";
-                                if (!packed) break;
-                            }
+                            s << ind << "const real q" << c.b << " = gf_rcp(" << N(c.b) << ");\n";
+                            s << ind << "dmax = __builtin_elementwise_maximum(dmax, gf_magnitude(" << N(c.b) << "));\n";
+                            s << ind << "dmin = __builtin_elementwise_minimum(dmin, gf_magnitude(" << N(c.b) << "));\n";
                         }
-                        s << ind << "const " << VT << " r" << i << " = gf_div(" << N(c.a) << ", " << N(c.b) << ", q" << c.b << ");\n";
+                        if (track_numerators) {
+                            s << ind << "nmin = __builtin_elementwise_min(nmin, gf_numerator_key(" << N(c.a) << "));\n";
+                        }
+                        s << ind << "const real r" << i << " = gf_div(" << N(c.a) << ", " << N(c.b) << ", q" << c.b << ");\n";
                     } else {
-                        s << ind << "const " << VT << " r" << i << " = " << N(c.a) << "/" << N(c.b) << ";\n";
+                        s << ind << "const real r" << i << " = " << N(c.a) << "/" << N(c.b) << ";\n";
                     }
                     break;
                 case GFIR_FMA:
-                    s << ind << "const " << VT << " r" << i << " = " << (packed ? std::string("gf_fma2") : "__builtin_fma" + std::string(sfx)) << "(" << N(c.a) << ", " << N(c.b)
+                    s << ind << "const real r" << i << " = __builtin_fma" << sfx << "(" << N(c.a) << ", " << N(c.b)
                       << ", " << N(c.c) << ");\n";
                     break;
                 case GFIR_SQRT:
-                    s << ind << "const " << VT << " r" << i << " = " << (packed ? std::string("gf_sqrt2") : "__builtin_sqrt" + std::string(sfx)) << "(" << N(c.a) << ");\n";
+                    s << ind << "const real r" << i << " = __builtin_sqrt" << sfx << "(" << N(c.a) << ");\n";
                     break;
                 case GFIR_POWI: {
-                    s << ind << "const " << VT << " r" << i << " = " << N(c.a);
+                    s << ind << "const real r" << i << " = " << N(c.a);
                     for (uint32_t k = 1; k < c.aux; k++) s << "*" << N(c.a);
                     s << ";\n";
                     break;
                 }
                 case GFIR_POW:
                     if (f64 && opt.pow_three_halves && it.code[c.b].op == GFIR_CONST && it.code[c.b].imm[0] == 1.5) {
-                        s << ind << "const " << VT << " r" << i << " = gf_pow_three_halves(r" << c.a << ");\n";
+                        s << ind << "const real r" << i << " = gf_pow_three_halves(" << N(c.a) << ");\n";
                     } else {
-                        s << ind << "const " << VT << " r" << i << " = " << (packed ? std::string("gf_pow2") : "pow" + std::string(sfx)) << "(" << N(c.a) << ", " << N(c.b) << ");\n";
+                        s << ind << "const real r" << i << " = pow" << sfx << "(" << N(c.a) << ", " << N(c.b) << ");\n";
                     }
                     break;
                 case GFIR_SIN:
-                    s << ind << "const " << VT << " r" << i << " = " << (packed ? std::string("gf_sin2") : "sin" + std::string(sfx)) << "(" << N(c.a) << ");\n";
+                    s << ind << "const real r" << i << " = sin" << sfx << "(" << N(c.a) << ");\n";
                     break;
                 case GFIR_COS:
-                    s << ind << "const " << VT << " r" << i << " = " << (packed ? std::string("gf_cos2") : "cos" + std::string(sfx)) << "(" << N(c.a) << ");\n";
+                    s << ind << "const real r" << i << " = cos" << sfx << "(" << N(c.a) << ");\n";
                     break;
                 case GFIR_ATAN2:
-                    s << ind << "const " << VT << " r" << i << " = " << (packed ? std::string("gf_atan22") : "atan2" + std::string(sfx)) << "(" << N(c.b) << ", " << N(c.a) << ");\n";
+                    s << ind << "const real r" << i << " = atan2" << sfx << "(" << N(c.b) << ", " << N(c.a) << ");\n";
                     break;
                 case GFIR_EXP:
-                    s << ind << "const " << VT << " r" << i << " = " << (packed ? std::string("gf_exp2") : "exp" + std::string(sfx)) << "(" << N(c.a) << ");\n";
+                    s << ind << "const real r" << i << " = exp" << sfx << "(" << N(c.a) << ");\n";
                     break;
                 case GFIR_LOG:
-                    s << ind << "const " << VT << " r" << i << " = " << (packed ? std::string("gf_log2") : "log" + std::string(sfx)) << "(" << N(c.a) << ");\n";
+                    s << ind << "const real r" << i << " = log" << sfx << "(" << N(c.a) << ");\n";
                     break;
                 case GFIR_GATHER1:
                 case GFIR_GATHER2: {
@@ -343,34 +274,14 @@ struct kernel_writer {
                                         c.imm[0], c.imm[1], two ? c.imm[2] : 0.0, two ? c.imm[3] : 0.0);
                     auto g = groups.find(key);
                     if (g == groups.end()) {
-                        const std::string name = "g" + std::to_string(group_count++);
+                        const std::string group_name = "g" + std::to_string(group_count++);
                         const pack &p = out.packs[table_pack[c.aux]];
-                        if (packed) {
-                            s << ind << "const real2 " << name << "_x = " << index_expression(c.a, c.imm[0], c.imm[1], two ? t.rows : t.cols) << ";\n";
-                            if (two) {
-                                s << ind << "const real2 " << name << "_y = " << index_expression(c.b, c.imm[2], c.imm[3], t.cols) << ";\n";
-                            }
-                            for (int component = 0; component < 2; component++) {
-                                const char *member = component ? ".y" : ".x";
-                                s << ind << "const unsigned int " << name << "_" << component << " = (static_cast<unsigned int> ("
-                                  << name << "_x" << member << ")";
-                                if (two) {
-                                    s << "*" << t.cols << "u + static_cast<unsigned int> (" << name << "_y" << member << ")";
-                                }
-                                s << ")*" << p.stride << "u;\n";
-                            }
-                            g = groups.insert({key, name}).first;
-                        } else {
-                        s << ind << "const unsigned int " << name << " = (";
-                        if (two) {
-                            s << index_expression(c.a, c.imm[0], c.imm[1], t.rows) << "*" << t.cols << "u + "
-                              << index_expression(c.b, c.imm[2], c.imm[3], t.cols);
-                        } else {
-                            s << index_expression(c.a, c.imm[0], c.imm[1], t.cols);
-                        }
+                        const std::string first = index_expression(c.a, c.imm[0], c.imm[1], two ? t.rows : t.cols);
+                        const std::string second = two ? index_expression(c.b, c.imm[2], c.imm[3], t.cols) : std::string();
+                        s << ind << "const unsigned int " << group_name << " = (" << first;
+                        if (two) s << "*" << t.cols << "u + " << second;
                         s << ")*" << p.stride << "u;\n";
-                        g = groups.insert({key, name}).first;
-                        }
+                        g = groups.insert({key, group_name}).first;
                     }
 //  A derived table's value (k*parent) is defined at its first use, not here: next to the
 //  parent's load it would make the pass wait for that load at once.  The load stays here.
@@ -382,7 +293,7 @@ struct kernel_writer {
                         break;
                     }
                     const std::string value = value_at(g->second, c.aux);
-                    s << ind << "const " << VT << " r" << i << " = " << value << ";\n";
+                    s << ind << "const real r" << i << " = " << value << ";\n";
                     break;
                 }
                 default:
@@ -401,22 +312,22 @@ struct kernel_writer {
         for (size_t o = 0; o < it.outputs.size(); o++) {
             s << ind << "so" << o << " = " << N(it.outputs[o]) << ";\n";
         }
-        }
+    }
 
-    void kernel(const bool converge) {
-        signature(converge);
+    void kernel(const entry which) {
+        signature(which);
         lds_setup();
-        tile_open(converge);
-        pass_open(converge);
-        pass(converge);
-        stores();
+        tile_open(which);
+        pass_open(which);
+        pass(which);
+        stores(which);
     }
 
 //  Kernel name, arguments.
-    void signature(const bool converge) {
+    void signature(const entry which) {
         s << "extern \"C\" __global__ void __launch_bounds__(" << out.block_size;
         if (opt.waves_per_simd) s << ", " << opt.waves_per_simd;
-        s << ")\n" << out.kernel_name << (converge ? "_converge" : "") << "(";
+        s << ")\n" << out.kernel_name << (which == entry::converge ? "_converge" : which == entry::max ? "_max" : "") << "(";
         for (size_t i = 0; i < it.symbols.size(); i++) {
             s << (out.input_written[i] ? "" : "const ") << "real *__restrict__ in" << i << ", ";
         }
@@ -426,11 +337,16 @@ struct kernel_writer {
         for (size_t p = 0; p < out.packs.size(); p++) {
             s << "const real *__restrict__ pack" << p << ", ";
         }
-        if (converge) {
-            s << "unsigned int *__restrict__ flags, const unsigned long long n, const real tolerance,\n"
-              << "        const unsigned int max_iterations, unsigned int *__restrict__ iterations) {\n";
+        s << "unsigned int *__restrict__ flags, const unsigned long long n, ";
+        if (which == entry::converge) {
+            s << "const real tolerance,\n        const unsigned int max_iterations, unsigned int *__restrict__ iterations) {\n";
+        } else if (which == entry::max) {
+            s << "const unsigned int steps,\n        unsigned long long *__restrict__ reduce, const unsigned int *__restrict__ stop) {\n"
+//  A converge loop enqueues its passes ahead of the host (gf_hip.cpp): once the loop's test has
+//  come out false on the device, the passes still in the queue must not touch the state.
+              << "    if (stop && *stop) return;\n";
         } else {
-            s << "unsigned int *__restrict__ flags, const unsigned long long n, const unsigned int steps) {\n";
+            s << "const unsigned int steps) {\n";
         }
     }
 
@@ -464,134 +380,80 @@ struct kernel_writer {
     }
 
 //  The grid-stride loop over tiles and the loads of a tile's state.
-    void tile_open(const bool converge) {
-        if (E > 1) {
-            s << "    typedef real vec_t __attribute__((ext_vector_type(" << E << ")));\n";
-            s << "    const bool aligned = ((0";
-            for (size_t i = 0; i < it.symbols.size(); i++) s << " | reinterpret_cast<unsigned long long> (in" << i << ")";
-            for (size_t o = 0; o < it.outputs.size(); o++) s << " | reinterpret_cast<unsigned long long> (out" << o << ")";
-            s << ") & " << (E*esize - 1) << "ull) == 0;\n";
+    void tile_open(const entry which) {
+        if (which == entry::max) {
+            s << "    real lane_max = -__builtin_huge_val" << sfx << "();\n";
         }
-        s << "    const unsigned long long groups = (n + " << (E - 1) << "ull)/" << E << "ull;\n";
-        prefetch = opt.prefetch_next_tile && E == 1 && !converge;
-        if (prefetch) {
-//  Software pipelining across grid-stride tiles: at one wave per SIMD nothing else hides the
-//  HBM latency of a tile's first loads, so they are issued one tile ahead.
-            s << "    const unsigned long long stride = gridDim.x*static_cast<unsigned long long> (blockDim.x);\n";
-            s << "    unsigned long long g = blockIdx.x*static_cast<unsigned long long> (blockDim.x) + threadIdx.x;\n";
-            for (size_t i = 0; i < it.symbols.size(); i++) {
-                s << "    real next" << i << " = g < groups ? in" << i << "[g] : " << literal(0.0) << ";\n";
-            }
-            if (opt.pipeline_tiles) {
-//  Results of the previous tile, stored one tile late (see the body).
-                s << "    bool have_pending = false;\n    unsigned long long pending_index = 0;\n";
-                for (size_t i = 0; i < it.symbols.size(); i++) {
-                    if (out.input_written[i]) s << "    real pending_v" << i << " = " << literal(0.0) << ";\n";
-                }
-                for (size_t o = 0; o < it.outputs.size(); o++) {
-                    s << "    real pending_o" << o << " = " << literal(0.0) << ";\n";
-                }
-            }
-            s << "    for (; g < groups; g += stride) {\n";
-        } else {
-            s << "    for (unsigned long long g = blockIdx.x*static_cast<unsigned long long> (blockDim.x) + threadIdx.x; g < groups;\n"
-              << "         g += gridDim.x*static_cast<unsigned long long> (blockDim.x)) {\n";
-        }
-        s << "        const unsigned long long i = g*" << E << "ull;\n";
-        if (E > 1) {
-            s << "        const bool full = aligned && i + " << E << "ull <= n;\n";
-        }
+        s << "    for (unsigned long long i = blockIdx.x*static_cast<unsigned long long> (blockDim.x) + threadIdx.x; i < n;\n"
+          << "         i += gridDim.x*static_cast<unsigned long long> (blockDim.x)) {\n";
         for (size_t i = 0; i < it.symbols.size(); i++) {
             std::string symbol = it.symbols[i];
             for (auto &ch : symbol) {
-                if (ch == '\\' || ch == '\n') ch = ' ';
+                if (ch == '\\' || ch == '\n' || ch == '\r') ch = ' ';
             }
-            s << "        real v" << i << "[" << E << "];  // " << symbol << "\n";
-            if (E > 1) {
-//  (loaded below, all arrays under one branch)
-            } else if (prefetch) {
-                s << "        v" << i << "[0] = next" << i << ";\n";
-            } else {
-                s << "        v" << i << "[0] = in" << i << "[i];\n";
-            }
-        }
-        if (E > 1) {
-            s << "        if (full) {\n";
-            for (size_t i = 0; i < it.symbols.size(); i++) {
-                s << "            const vec_t t" << i << " = *reinterpret_cast<const vec_t *> (in" << i << " + i);\n";
-            }
-            for (size_t i = 0; i < it.symbols.size(); i++) {
-                s << "            for (unsigned int e = 0; e < " << E << "u; e++) v" << i << "[e] = t" << i << "[e];\n";
-            }
-            s << "        } else {\n";
-            for (size_t i = 0; i < it.symbols.size(); i++) {
-                s << "            for (unsigned int e = 0; e < " << E << "u; e++) v" << i << "[e] = i + e < n ? in" << i << "[i + e] : "
-                  << (packed ? "in" + std::to_string(i) + "[i]" : literal(0.0)) << ";\n";
-            }
-            s << "        }\n";
+            s << "        real v" << i << " = in" << i << "[i];  // " << symbol << "\n";
         }
         for (size_t o = 0; o < it.outputs.size(); o++) {
-            s << "        real o" << o << "[" << E << "] = {};\n";
+            s << "        real o" << o << " = " << literal(0.0) << ";\n";
         }
     }
 
 //  One pass over the tile: the per-ray converge loop, or `steps` passes of the body.
-    void pass_open(const bool converge) {
-        if (converge) {
+    void pass_open(const entry which) {
+        if (which == entry::converge) {
             s << "        unsigned int count = 0;\n"
               << "        bool active = true;\n"
               << "        real last_max = " << (f64 ? "__DBL_MAX__" : "__FLT_MAX__") << ", off_last_max = last_max;\n"
               << "        for (;;) {\n"
-              << "            if (active) {\n"
-              << "            const unsigned int e = 0;\n";
-        } else if (packed) {
-            for (size_t i = 0; i < it.symbols.size(); i++) {
-                s << "        real2 V" << i << " = {v" << i << "[0], v" << i << "[1]};\n";
-            }
-            for (size_t o = 0; o < it.outputs.size(); o++) {
-                s << "        real2 O" << o << " = {};\n";
-            }
-            s << "        for (unsigned int step = 0; step < steps; step++) {\n";
-            s << "            {\n";
+              << "            if (active) {\n";
         } else {
             s << "        for (unsigned int step = 0; step < steps; step++) {\n";
-            if (E > 1) {
-                s << "            #pragma unroll\n";
-            }
-            s << "            for (unsigned int e = 0; e < " << E << "u; e++) {\n";
-            if (E > 1) {
-                s << "            if (i + e >= n) continue;\n";
-            }
+            s << "            {\n";
         }
         for (size_t k = 0; k < it.setters.size(); k++) {
-            s << "            " << VT << " sv" << k << ";\n";
+            s << "            real sv" << k << ";\n";
         }
         for (size_t o = 0; o < it.outputs.size(); o++) {
-            s << "            " << VT << " so" << o << ";\n";
+            s << "            real so" << o << ";\n";
         }
     }
 
-//  The body with its window check, the write-back into the lane's state, the end of the pass loop.
-    void pass(const bool converge) {
+//  The body with its checks and its IEEE second body, the write-back into the lane's state,
+//  the end of the pass loop.
+    void pass(const entry which) {
         if (use_shared) {
-//  A lane whose denominators leave the window in which the unscaled sequence is the IEEE one
-//  (or whose results are not finite) raises a flag the host reports at the next wait():
-//  results are then not guaranteed bit-identical and the item should be rebuilt with
-//  GFHIP_DIVISION=ieee.  Never observed on the hot-path workloads (|d| spans 1e-30..1e+30).
             s << "            bool bad = false;\n";
-            s << "            float dmax = gf_magnitude(" << literal(1.0) << "), dmin = dmax;   // extreme |denominator| of this pass\n";
             s << "            {\n";
+            s << "                float dmax = gf_magnitude(" << literal(1.0) << "), dmin = dmax;   // extreme |denominator| of this pass\n";
+            s << "                real finite_check = " << literal(0.0) << ";\n";
+            if (track_numerators) s << "                unsigned int nmin = 0xFFFFFFFFu;                    // smallest non-zero |numerator| key\n";
             body(true);
-            s << "                " << VT << " finite_check = " << literal(0.0) << ";\n";
-            for (size_t k = 0; k < it.setters.size(); k++) s << "                finite_check += sv" << k << ";\n";
-            for (size_t o = 0; o < it.outputs.size(); o++) s << "                finite_check += so" << o << ";\n";
-            s << "                bad = !__builtin_isfinite(" << (packed ? "finite_check.x + finite_check.y" : "finite_check") << ") || !(dmin >= gf_magnitude(" << (f64 ? "0x1p-500" : "0x1p-100f")
-              << ")) || !(dmax <= gf_magnitude(" << (f64 ? "0x1p+500" : "0x1p+100f") << "));\n";
+            std::vector<std::string> quotient_results;
+            for (size_t k = 0; k < it.setters.size(); k++) {
+                s << "                finite_check += sv" << k << ";\n";
+                if (after_division[it.setters[k].value]) quotient_results.push_back("sv" + std::to_string(k));
+            }
+            for (size_t o = 0; o < it.outputs.size(); o++) {
+                s << "                finite_check += so" << o << ";\n";
+                if (after_division[it.outputs[o]]) quotient_results.push_back("so" + std::to_string(o));
+            }
+//  Windows: see the contract at the top of prelude.hpp.
+            const char *low = f64 ? "0x1p-500" : (track_numerators ? "0x1p-60f" : "0x1p-100f");
+            const char *high = f64 ? "0x1p+500" : (track_numerators ? "0x1p+60f" : "0x1p+100f");
+            s << "                bad = !__builtin_isfinite(finite_check) || !(dmin >= gf_magnitude(" << low
+              << ")) || !(dmax <= gf_magnitude(" << high << "))";
+            for (auto &value : quotient_results) s << " || " << value << " == " << literal(0.0);
+            if (track_numerators) s << " || nmin < gf_numerator_key(" << (f64 ? "0x1p-450" : "0x1p-60f") << ")";
+            s << ";\n";
             s << "            }\n";
-//  Set the status bit once: lanes that find it set only read it (an atomic per flagged lane on
-//  one address serialises at ~11 ns each — 0.7 ms for 1e7 flagged lanes).
+//  Lanes that failed a check redo the pass with the compiler's IEEE division (the inputs of the
+//  pass are still in v*).  The status bit is set once: lanes that find it set only read it (an
+//  atomic per flagged lane on one address serialises at ~11 ns each).
             s << "            if (__builtin_expect(bad, 0)) {\n"
               << "                if (__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) atomicOr(flags, 1u);\n"
+              << "                {\n";
+            body(false);
+            s << "                }\n"
               << "            }\n";
         } else {
             s << "            {\n";
@@ -599,13 +461,12 @@ struct kernel_writer {
             s << "            }\n";
         }
         for (size_t o = 0; o < it.outputs.size(); o++) {
-            s << "            " << (packed ? "O" + std::to_string(o) : "o" + std::to_string(o) + "[e]") << " = so" << o << ";\n";
+            s << "            o" << o << " = so" << o << ";\n";
         }
         for (size_t k = 0; k < it.setters.size(); k++) {
-            const std::string input = std::to_string(it.setters[k].input);
-            s << "            " << (packed ? "V" + input : "v" + input + "[e]") << " = sv" << k << ";\n";
+            s << "            v" << it.setters[k].input << " = sv" << k << ";\n";
         }
-        if (converge) {
+        if (which == entry::converge) {
 //  converge_item::run for this ray:  while (A && B && C && iterations++ < max) {...}
             const std::string fabs_ = std::string("__builtin_fabs") + (f64 ? "" : "f");
             s << "            const real residual = so" << it.outputs.size() - 1 << ";\n"
@@ -622,66 +483,45 @@ struct kernel_writer {
         } else {
             s << "            }\n";
             s << "        }\n";
-            if (packed) {
-                for (size_t i = 0; i < it.symbols.size(); i++) {
-                    if (out.input_written[i]) s << "        v" << i << "[0] = V" << i << ".x; v" << i << "[1] = V" << i << ".y;\n";
-                }
-                for (size_t o = 0; o < it.outputs.size(); o++) {
-                    s << "        o" << o << "[0] = O" << o << ".x; o" << o << "[1] = O" << o << ".y;\n";
-                }
-            }
         }
     }
 
-    void stores() {
+    void stores(const entry which) {
 //  Stores: setters first, then outputs (cpu_context.hpp:522-580).
-        std::vector<std::pair<std::string, std::string>> stores;               // (pointer, values)
         for (size_t i = 0; i < it.symbols.size(); i++) {
-            if (out.input_written[i]) stores.push_back({"in" + std::to_string(i), "v" + std::to_string(i)});
+            if (out.input_written[i]) s << "        in" << i << "[i] = v" << i << ";\n";
         }
         for (size_t o = 0; o < it.outputs.size(); o++) {
-            stores.push_back({"out" + std::to_string(o), "o" + std::to_string(o)});
+            s << "        out" << o << "[i] = o" << o << ";\n";
         }
-        if (E > 1) {
-            s << "        if (full) {\n";
-            for (auto &st : stores) {
-                s << "            {\n"
-                  << "                vec_t t;\n"
-                  << "                for (unsigned int e = 0; e < " << E << "u; e++) t[e] = " << st.second << "[e];\n"
-                  << "                *reinterpret_cast<vec_t *> (" << st.first << " + i) = t;\n"
-                  << "            }\n";
-            }
-            s << "        } else {\n";
-            for (auto &st : stores) {
-                s << "            for (unsigned int e = 0; e < " << E << "u; e++) if (i + e < n) " << st.first << "[i + e] = " << st.second << "[e];\n";
-            }
-            s << "        }\n";
-        } else if (prefetch && opt.pipeline_tiles) {
-//  Keep this tile's results; they are stored from inside the next tile (or after the loop).
-            for (size_t i = 0; i < it.symbols.size(); i++) {
-                if (out.input_written[i]) s << "        pending_v" << i << " = v" << i << "[0];\n";
-            }
-            for (size_t o = 0; o < it.outputs.size(); o++) {
-                s << "        pending_o" << o << " = o" << o << "[0];\n";
-            }
-            s << "        pending_index = i;\n        have_pending = true;\n";
-            s << "    }\n";
-            s << "    if (have_pending) {\n";
-            for (size_t i = 0; i < it.symbols.size(); i++) {
-                if (out.input_written[i]) s << "        in" << i << "[pending_index] = pending_v" << i << ";\n";
-            }
-            for (size_t o = 0; o < it.outputs.size(); o++) {
-                s << "        out" << o << "[pending_index] = pending_o" << o << ";\n";
-            }
-            s << "    }\n}\n";
-            return;
-        } else {
-            for (auto &st : stores) {
-                s << "        " << st.first << "[i] = " << st.second << "[0];\n";
-            }
+        if (which == entry::max) {
+//  The max of the last output (create_max_call's argument), as the CUDA reduction's `max` takes
+//  it (cuda_context.hpp:954-995): a NaN is never selected.
+            const std::string last = "o" + std::to_string(it.outputs.size() - 1);
+            s << "        lane_max = " << last << " > lane_max ? " << last << " : lane_max;\n";
         }
-        s << "    }\n}\n";
-        
+        s << "    }\n";
+        if (which == entry::max) {
+//  Epilogue of create_max_call: 64-lane shuffle reduction, one LDS word per wave, ONE
+//  device-scope atomicMax per workgroup on an order-preserving integer image of the value
+//  (max is exact and order independent: the same bits as a serial scan).
+            const char *bits = f64 ? "unsigned long long" : "unsigned int";
+            s << "    for (int offset = 32; offset > 0; offset >>= 1) {\n"
+              << "        const real other = __shfl_down(lane_max, offset, 64);\n"
+              << "        lane_max = other > lane_max ? other : lane_max;\n"
+              << "    }\n"
+              << "    __shared__ real wave_max[" << out.block_size/64 << "];\n"
+              << "    if ((threadIdx.x & 63u) == 0u) wave_max[threadIdx.x >> 6] = lane_max;\n"
+              << "    __syncthreads();\n"
+              << "    if (threadIdx.x == 0u) {\n"
+              << "        real block_max = wave_max[0];\n"
+              << "        for (unsigned int w = 1; w < (blockDim.x >> 6); w++) block_max = wave_max[w] > block_max ? wave_max[w] : block_max;\n"
+              << "        const " << bits << " b = __builtin_bit_cast(" << bits << ", block_max);\n"
+              << "        const " << bits << " top = static_cast<" << bits << "> (1) << " << (f64 ? 63 : 31) << ";\n"
+              << "        atomicMax(reduce, static_cast<unsigned long long> ((b & top) ? static_cast<" << bits << "> (~b) : (b | top)));\n"
+              << "    }\n";
+        }
+        s << "}\n";
     }
 };
 
@@ -690,26 +530,12 @@ struct kernel_writer {
 //------------------------------------------------------------------------------
 inline lowered lower(const item &original, const codegen_options &opt = codegen_options::from_environment()) {
     item scheduled;
-    if (const char *path = std::getenv("GFHIP_ORDER_FILE")) {   // EXPERIMENT: an explicit emission order
-        std::ifstream f(path);
-        std::vector<uint32_t> order;
-        std::vector<uint32_t> fences;                           // 4294967295 in the file = a fence before the next record
-        for (uint32_t v; f >> v;) {
-            if (v == GFIR_NONE) fences.push_back(static_cast<uint32_t> (order.size())); else order.push_back(v);
-        }
-        if (order.size() == original.code.size()) {
-            scheduled = reorder(original, order);
-            scheduled.fences = fences;
-        }
-    } else if (opt.schedule_for_pressure) {
+    if (opt.schedule_for_pressure) {
         scheduled = schedule_for_pressure(original);
     }
     const item &it = scheduled.code.empty() ? original : scheduled;
     lowered out;
-    const bool f64 = it.dtype == GFIR_F64;
-    const std::string sfx = f64 ? "" : "f";
     const size_t esize = it.element_size();
-
 
 //  Which inputs are overwritten.
     out.input_written.assign(it.symbols.size(), false);
@@ -727,51 +553,47 @@ inline lowered lower(const item &original, const codegen_options &opt = codegen_
     size_t lds_used = layout.lds_used;
     out.block_size = opt.block_size;
 
-//  Rays per lane.  A lane that owns ONE 4- or 8-byte element issues 4/8-byte loads; small
-//  items are HBM bound (xkorc step: 56 B and ~200 flops per particle) and want 16 B per lane
-//  per access, so a lane owns 4 (fp32) or 2 (fp64) CONSECUTIVE rays: vector loads/stores and
-//  2-4 independent instruction streams per lane.  Large items (the RK4 step) keep one ray per
-//  lane — they are register bound.
-    uint32_t elements = opt.elements_per_lane;
-    if (elements == 0) {
-//  Measured (MI355X, xkorc 1e7 particles, loss_kernel 1e6 rays): 2 or 4 rays per lane are
-//  not faster than 1 — these items are issue bound by their divisions, not by load width.
-        elements = 1;
-    }
-    if (elements != 1 && elements != 2 && elements != 4) elements = 1;
-//  Packed pairs (fp32 only): a lane owns two consecutive rays held as ONE float2, so that the
-//  arithmetic of the pass issues as v_pk_add/mul/fma_f32 — two rays per VALU slot instead of
-//  one (CDNA's fp32 vector peak is a packed-math figure).  Same IEEE operations per component.
-    const bool packed = it.dtype == GFIR_F32 && opt.packed_pairs == 1;
-    if (packed) elements = 2;
-    out.elements = elements;
-
     uint32_t park_slots = 0;
-    const std::vector<park_plan> plan = plan_parking(it, opt, lds_used, esize, elements, park_slots);
+    const std::vector<park_plan> plan = plan_parking(it, opt, lds_used, esize, park_slots);
     const size_t park_offset = lds_used;
     lds_used += static_cast<size_t> (park_slots)*opt.block_size*esize;
     out.lds_bytes = lds_used;
     out.park_slots = park_slots;
 
+//  Nodes that depend on the result of a division (a stored zero among them may carry the wrong
+//  sign without v_div_fixup), and whether the item divides at all.
+    std::vector<bool> after_division(it.code.size(), false);
+    bool divides = false;
+    for (size_t i = 0; i < it.code.size(); i++) {
+        const gfir_instruction &c = it.code[i];
+        const uint32_t operands[3] = {c.a, c.b, c.c};
+        bool dependent = c.op == GFIR_DIV;
+        divides = divides || dependent;
+        for (int k = 0; k < operand_count(c.op) && !dependent; k++) dependent = after_division[operands[k]];
+        after_division[i] = dependent;
+    }
+
     std::ostringstream s;
     out.kernel_name = "gfhip_" + it.name;
-    emit_prelude(s, it, opt, out.packs.size(), packed);
-    const bool use_shared = opt.shared_reciprocal;
-//  Two entry points per item: `<name>` runs `steps` passes; `<name>_converge` (items with a
-//  setter and an output, one ray per lane) runs the stall loop of workflow.hpp:179-205 PER RAY
-//  inside the launch — every lane iterates on its own residual, a wavefront leaves the loop
-//  when the ballot of still-active lanes is empty.  That is the reference's converge loop
-//  applied to each ray as its own shard; it equals the reference's global-max loop when the
-//  rays are identical (the benchmark) and is offered as gfhip_converge_per_ray.
-    const bool has_converge = !it.setters.empty() && !it.outputs.empty() && elements == 1 &&
-                              it.code.size() <= 1500;
-    out.has_converge = has_converge;
+    emit_prelude(s, it, opt, out.packs.size());
+//  Items without a division node need neither the checks nor the second body (their gather
+//  indices then divide by the literal scale).
+    const bool use_shared = opt.division != division_mode::ieee && divides;
+//  Entry points: `<name>` runs `steps` passes.  Small items with an output also get `<name>_max`
+//  (the same, plus the max of the last output reduced inside the launch: create_max_call) and,
+//  with a setter, `<name>_converge`, which runs the stall loop of workflow.hpp:179-205 PER RAY
+//  inside the launch — every lane iterates on its own residual, a wavefront leaves the loop when
+//  the ballot of still-active lanes is empty.  That is the reference's converge loop applied to
+//  each ray as its own shard; it equals the reference's global-max loop when the rays are
+//  identical (the benchmark) and is offered as gfhip_converge_per_ray.
+    const bool small = it.code.size() <= 1500;
+    out.has_max = !it.outputs.empty() && small;
+    out.has_converge = out.has_max && !it.setters.empty();
     kernel_writer writer{s, it, opt, out, parent, factor, table_pack, table_column, plan, lds_used, park_offset, park_slots,
-                         elements, packed, use_shared};
-    writer.kernel(false);
-    if (has_converge) {
-        writer.kernel(true);
-    }
+                         use_shared, after_division};
+    writer.kernel(entry::plain);
+    if (out.has_max) writer.kernel(entry::max);
+    if (out.has_converge) writer.kernel(entry::converge);
 
     out.source = s.str();
     out.hash = fnv1a(out.source + "|" + compile_flags());

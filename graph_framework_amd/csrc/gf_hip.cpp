@@ -29,9 +29,12 @@
 #include "../../include/gf_hip.h"
 #include "codegen.hpp"
 
+#include "converge_state.hpp"
+
 namespace gfhip {
 void launch_max_reduce(const void *in, const size_t n, const bool f64,
                        unsigned long long *result, const unsigned int num_cus, hipStream_t stream);
+void launch_converge_decide(const bool f64, unsigned long long *reduced, void *state, hipStream_t stream);
 }
 
 namespace {
@@ -43,6 +46,7 @@ struct buffer {
     size_t count = 0;
     uint32_t dtype = GFIR_F64;
     bool owned = true;
+    void *mirror = nullptr;     // pinned host copy handed out by gfhip_get_host_buffer, refreshed by gfhip_wait
 };
 
 std::string library_directory() {
@@ -84,8 +88,9 @@ struct gfhip_context {
     std::string error;
     unsigned long long *device_scalar = nullptr;
     unsigned long long *host_scalar = nullptr;     // pinned
-    unsigned int *device_flags = nullptr;          // bit 0: a lane left the fast-division window
-    bool flags_reported = false;
+    unsigned int *device_flags = nullptr;          // bit 0: a lane redid a pass with the compiler's division
+    gfhip::converge_state *device_converge = nullptr;
+    gfhip::converge_state *host_converge = nullptr;   // pinned
     unsigned int timing = 0;                       // 0 = off, N = events around every Nth launch of a kernel
 
     int fail(const std::string &message) {
@@ -108,6 +113,8 @@ struct gfhip_kernel {
     hipModule_t module = nullptr;
     hipFunction_t function = nullptr;
     hipFunction_t converge_function = nullptr;
+    hipFunction_t max_function = nullptr;
+    bool built = false;
     bool from_cache = false;
     std::vector<void *> pack_device;
     std::vector<uint64_t> input_keys, output_keys;
@@ -117,6 +124,7 @@ struct gfhip_kernel {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
     uint64_t launch_count = 0;
+    std::vector<double> samples;                   // durations drained by the last gfhip_kernel_timing
 };
 
 #define GFHIP_TRY(ctx, call, what) do { if ((ctx)->check((call), (what))) return 1; } while (0)
@@ -175,7 +183,9 @@ extern "C" gfhip_context *gfhip_create_context(int index, void *stream) {
     if (hipMalloc(reinterpret_cast<void **> (&ctx->device_flags), sizeof(unsigned int)) != hipSuccess ||
         hipMemset(ctx->device_flags, 0, sizeof(unsigned int)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **> (&ctx->device_scalar), sizeof(unsigned long long)) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void **> (&ctx->host_scalar), sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
+        hipHostMalloc(reinterpret_cast<void **> (&ctx->host_scalar), sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **> (&ctx->device_converge), sizeof(gfhip::converge_state)) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void **> (&ctx->host_converge), sizeof(gfhip::converge_state), hipHostMallocDefault) != hipSuccess) {
         creation_error = "cannot allocate reduction scalars";
         gfhip_destroy_context(ctx.release());                  // frees whatever was allocated
         return nullptr;
@@ -199,7 +209,10 @@ extern "C" void gfhip_destroy_context(gfhip_context *ctx) {
     for (auto &k : ctx->kernels) release_kernel(k.get());
     for (auto &kv : ctx->buffers) {
         if (kv.second.owned && kv.second.pointer) (void)hipFree(kv.second.pointer);
+        if (kv.second.mirror) (void)hipHostFree(kv.second.mirror);
     }
+    if (ctx->device_converge) (void)hipFree(ctx->device_converge);
+    if (ctx->host_converge) (void)hipHostFree(ctx->host_converge);
     if (ctx->device_scalar) (void)hipFree(ctx->device_scalar);
     if (ctx->device_flags) (void)hipFree(ctx->device_flags);
     if (ctx->host_scalar) (void)hipHostFree(ctx->host_scalar);
@@ -238,7 +251,9 @@ extern "C" void gfhip_free_string(char *text) {
     std::free(text);
 }
 
-//  Build one kernel: cached code object (by source hash) or hipRTC.
+//  Build one kernel: cached code object (by source hash) or hipRTC.  Module, functions and
+//  packs are built into locals and committed to the kernel only when every step has succeeded,
+//  so a failed build leaves nothing half-initialised behind (a later gfhip_compile retries).
 static int build_kernel(gfhip_context *ctx, gfhip_kernel *k) {
     const std::string file = hash_name(k->low.hash) + ".hsaco";
     std::vector<std::string> directories;
@@ -246,14 +261,15 @@ static int build_kernel(gfhip_context *ctx, gfhip_kernel *k) {
     directories.push_back(library_directory() + "/kernel_cache");
 
     std::vector<char> code;
+    bool from_cache = false;
     for (auto &d : directories) {
         if (read_file(d + "/" + file, code)) {
-            k->from_cache = true;
+            from_cache = true;
             break;
         }
     }
 
-    if (!k->from_cache) {
+    if (!from_cache) {
         if (std::getenv("GFHIP_REQUIRE_CACHE")) {
             return ctx->fail("kernel " + k->item.name + " (" + file + ") not in the kernel cache and GFHIP_REQUIRE_CACHE is set");
         }
@@ -283,24 +299,37 @@ static int build_kernel(gfhip_context *ctx, gfhip_kernel *k) {
         }
     }
 
-    GFHIP_TRY(ctx, hipModuleLoadData(&k->module, code.data()), "hipModuleLoadData");
-    GFHIP_TRY(ctx, hipModuleGetFunction(&k->function, k->module, k->low.kernel_name.c_str()), "hipModuleGetFunction");
-    if (k->low.has_converge) {
-        GFHIP_TRY(ctx, hipModuleGetFunction(&k->converge_function, k->module, (k->low.kernel_name + "_converge").c_str()),
-                  "hipModuleGetFunction(converge)");
-    }
-    (void)hipFuncGetAttribute(&k->vgprs, HIP_FUNC_ATTRIBUTE_NUM_REGS, k->function);
-    (void)hipFuncGetAttribute(&k->lds_static, HIP_FUNC_ATTRIBUTE_SHARED_SIZE_BYTES, k->function);
-    (void)hipFuncGetAttribute(&k->scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, k->function);
+    hipModule_t module = nullptr;
+    hipFunction_t function = nullptr, max_function = nullptr, converge_function = nullptr;
+    std::vector<void *> packs(k->low.packs.size(), nullptr);
+    auto abandon = [&] (const int status) {
+        for (void *p : packs) {
+            if (p) (void)hipFree(p);
+        }
+        if (module) (void)hipModuleUnload(module);
+        return status;
+    };
+    if (ctx->check(hipModuleLoadData(&module, code.data()), "hipModuleLoadData")) return abandon(1);
+    if (ctx->check(hipModuleGetFunction(&function, module, k->low.kernel_name.c_str()), "hipModuleGetFunction")) return abandon(1);
+    if (k->low.has_max &&
+        ctx->check(hipModuleGetFunction(&max_function, module, (k->low.kernel_name + "_max").c_str()),
+                   "hipModuleGetFunction(max)")) return abandon(1);
+    if (k->low.has_converge &&
+        ctx->check(hipModuleGetFunction(&converge_function, module, (k->low.kernel_name + "_converge").c_str()),
+                   "hipModuleGetFunction(converge)")) return abandon(1);
+    int vgprs = 0, lds_static = 0, scratch = 0;
+    (void)hipFuncGetAttribute(&vgprs, HIP_FUNC_ATTRIBUTE_NUM_REGS, function);
+    (void)hipFuncGetAttribute(&lds_static, HIP_FUNC_ATTRIBUTE_SHARED_SIZE_BYTES, function);
+    (void)hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, function);
     if (k->low.lds_bytes > 48*1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *> (k->function),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  static_cast<int> (k->low.lds_bytes));
+        for (hipFunction_t f : {function, max_function, converge_function}) {
+            if (f) (void)hipFuncSetAttribute(reinterpret_cast<const void *> (f), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             static_cast<int> (k->low.lds_bytes));
+        }
     }
 
 //  Pack and upload the tables: [cell][column], padded to the pack stride.
     const size_t esize = k->item.element_size();
-    k->pack_device.assign(k->low.packs.size(), nullptr);
     for (size_t p = 0; p < k->low.packs.size(); p++) {
         const gfhip::pack &pk = k->low.packs[p];
         const size_t cells = pk.cells();
@@ -315,15 +344,14 @@ static int build_kernel(gfhip_context *ctx, gfhip_kernel *k) {
                 }
             }
         }
-        GFHIP_TRY(ctx, hipMalloc(&k->pack_device[p], host.size()), "hipMalloc(pack)");
-        GFHIP_TRY(ctx, hipMemcpy(k->pack_device[p], host.data(), host.size(), hipMemcpyHostToDevice), "hipMemcpy(pack)");
+        if (ctx->check(hipMalloc(&packs[p], host.size() ? host.size() : 8), "hipMalloc(pack)")) return abandon(1);
+        if (ctx->check(hipMemcpy(packs[p], host.data(), host.size(), hipMemcpyHostToDevice), "hipMemcpy(pack)")) return abandon(1);
     }
 
 //  Launch geometry: one lane per ray; the kernel grid-strides, so cap the grid
 //  at a few waves of workgroups per CU.
     const size_t block = k->low.block_size;
-    const size_t groups = (k->num_rays + k->low.elements - 1)/k->low.elements;
-    size_t want = (groups + block - 1)/block;
+    size_t want = (k->num_rays + block - 1)/block;
     if (want < 1) want = 1;
 //  Persistent-style grid: a few workgroups per resident slot, the kernel grid-strides.
 //  Measured (1e7-particle fp64 push): exact grid 0.276 ms, 64 per CU 0.245, 16 per CU 0.235.
@@ -331,15 +359,26 @@ static int build_kernel(gfhip_context *ctx, gfhip_kernel *k) {
 //  per SIMD) run best with exactly one workgroup per CU: 0.279 vs 0.298 ms per step at 1e6
 //  rays (the coefficient packs are staged into LDS once per workgroup instead of 15 times).
     int resident = 0;
-    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&resident, k->function, static_cast<int> (block),
+    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&resident, function, static_cast<int> (block),
                                                            k->low.lds_bytes) != hipSuccess || resident < 1) {
         resident = 1;
     }
     size_t cap = static_cast<size_t> (ctx->num_cus)*static_cast<size_t> (resident)*(resident == 1 ? 1 : 4);
     if (const char *env = std::getenv("GFHIP_GRID_PER_CU")) {
-        cap = static_cast<size_t> (ctx->num_cus)*static_cast<size_t> (std::atoi(env));
+        cap = static_cast<size_t> (ctx->num_cus)*static_cast<size_t> (std::atoi(env) > 0 ? std::atoi(env) : 1);
     }
+
+    k->module = module;
+    k->function = function;
+    k->max_function = max_function;
+    k->converge_function = converge_function;
+    k->pack_device = packs;
+    k->vgprs = vgprs;
+    k->lds_static = lds_static;
+    k->scratch = scratch;
+    k->from_cache = from_cache;
     k->grid = static_cast<unsigned int> (want < cap ? want : cap);
+    k->built = true;
     return 0;
 }
 
@@ -347,7 +386,7 @@ extern "C" int gfhip_compile(gfhip_context *ctx) {
     if (!ctx) return 1;
     GFHIP_TRY(ctx, hipSetDevice(ctx->device), "hipSetDevice");
     for (auto &k : ctx->kernels) {
-        if (!k->function) {
+        if (!k->built) {
             if (build_kernel(ctx, k.get())) return 1;
         }
     }
@@ -355,18 +394,25 @@ extern "C" int gfhip_compile(gfhip_context *ctx) {
 }
 
 static int ensure_buffer(gfhip_context *ctx, const uint64_t key, const size_t count, const uint32_t dtype,
-                         const void *init) {
+                         const void *init, size_t init_count = ~static_cast<size_t> (0)) {
     auto found = ctx->buffers.find(key);
     if (found == ctx->buffers.end()) {
         buffer b;
         b.count = count;
         b.dtype = dtype;
-        const size_t bytes = count*(dtype == GFIR_F32 ? 4 : 8);
+        const size_t esize = dtype == GFIR_F32 ? 4 : 8;
+        const size_t bytes = count*esize;
+        if (init_count > count) init_count = count;
         GFHIP_TRY(ctx, hipMalloc(&b.pointer, bytes ? bytes : 8), "hipMalloc(buffer)");
-        if (init) {
-            GFHIP_TRY(ctx, hipMemcpy(b.pointer, init, bytes, hipMemcpyHostToDevice), "hipMemcpy(init)");
-        } else {
-            GFHIP_TRY(ctx, hipMemsetAsync(b.pointer, 0, bytes, ctx->stream), "hipMemset(buffer)");
+        if (!init || init_count < count) {
+            GFHIP_TRY(ctx, hipMemset(b.pointer, 0, bytes), "hipMemset(buffer)");
+        }
+        if (init && init_count) {
+            const hipError_t status = hipMemcpy(b.pointer, init, init_count*esize, hipMemcpyHostToDevice);
+            if (status != hipSuccess) {
+                (void)hipFree(b.pointer);
+                return ctx->check(status, "hipMemcpy(init)");
+            }
         }
         ctx->buffers[key] = b;
         return 0;
@@ -381,7 +427,8 @@ static int ensure_buffer(gfhip_context *ctx, const uint64_t key, const size_t co
 }
 
 extern "C" int gfhip_create_kernel_call(gfhip_kernel *k, const uint64_t *input_keys,
-                                        const void *const *input_init, const uint64_t *output_keys) {
+                                        const void *const *input_init, const size_t *input_counts,
+                                        const uint64_t *output_keys) {
     if (!k) return 1;
     gfhip_context *ctx = k->ctx;
     GFHIP_TRY(ctx, hipSetDevice(ctx->device), "hipSetDevice");
@@ -389,7 +436,8 @@ extern "C" int gfhip_create_kernel_call(gfhip_kernel *k, const uint64_t *input_k
     k->input_keys.assign(input_keys, input_keys + ni);
     k->output_keys.assign(output_keys, output_keys + no);
     for (size_t i = 0; i < ni; i++) {
-        if (ensure_buffer(ctx, input_keys[i], k->num_rays, k->item.dtype, input_init ? input_init[i] : nullptr)) return 1;
+        if (ensure_buffer(ctx, input_keys[i], k->num_rays, k->item.dtype, input_init ? input_init[i] : nullptr,
+                          input_counts ? input_counts[i] : k->num_rays)) return 1;
     }
     for (size_t o = 0; o < no; o++) {
         if (ensure_buffer(ctx, output_keys[o], k->num_rays, k->item.dtype, nullptr)) return 1;
@@ -412,11 +460,15 @@ extern "C" int gfhip_create_kernel_call(gfhip_kernel *k, const uint64_t *input_k
     return 0;
 }
 
-static int launch(gfhip_kernel *k, const uint32_t steps) {
+//  Launch `<name>` (reduce == nullptr) or `<name>_max` (the max of the last output is folded into
+//  *reduce; a non-null `stop` word that reads non-zero makes the launch return at once).
+static int launch(gfhip_kernel *k, const uint32_t steps, unsigned long long *reduce = nullptr,
+                  const unsigned int *stop = nullptr) {
     gfhip_context *ctx = k->ctx;
-    if (!k->function) return ctx->fail("kernel has not been compiled (gfhip_compile)");
+    if (!k->built) return ctx->fail("kernel has not been compiled (gfhip_compile)");
     if (!k->bound) return ctx->fail("kernel arguments are not bound (gfhip_create_kernel_call)");
     if (k->num_rays == 0 || steps == 0) return 0;
+    if (reduce && !k->max_function) return ctx->fail("item has no in-launch max reduction");
 
     std::vector<void *> pointers;
     for (auto key : k->input_keys) pointers.push_back(ctx->buffers[key].pointer);
@@ -429,6 +481,10 @@ static int launch(gfhip_kernel *k, const uint32_t steps) {
     for (auto &p : pointers) params.push_back(&p);
     params.push_back(&n);
     params.push_back(&step_count);
+    if (reduce) {
+        params.push_back(&reduce);
+        params.push_back(&stop);
+    }
 
     std::pair<hipEvent_t, hipEvent_t> ev;
     const bool timed = ctx->timing && (k->launch_count++ % ctx->timing) == 0;
@@ -442,7 +498,7 @@ static int launch(gfhip_kernel *k, const uint32_t steps) {
         }
         GFHIP_TRY(ctx, hipEventRecord(ev.first, ctx->stream), "hipEventRecord");
     }
-    GFHIP_TRY(ctx, hipModuleLaunchKernel(k->function, k->grid, 1, 1, k->low.block_size, 1, 1,
+    GFHIP_TRY(ctx, hipModuleLaunchKernel(reduce ? k->max_function : k->function, k->grid, 1, 1, k->low.block_size, 1, 1,
                                          static_cast<unsigned int> (k->low.lds_bytes), ctx->stream,
                                          params.data(), nullptr), "hipModuleLaunchKernel");
     if (timed) {
@@ -472,17 +528,28 @@ static double decode_ordered(const unsigned long long key, const bool f64) {
     return static_cast<double> (v);
 }
 
+//  One pass + the max of its last output left in ctx->device_scalar (ordered image), no sync:
+//  inside the launch for items that have `<name>_max`, else the separate reduction kernel.
+static int enqueue_pass_with_max(gfhip_kernel *k, const unsigned int *stop) {
+    gfhip_context *ctx = k->ctx;
+    if (k->max_function) {
+        return launch(k, 1, ctx->device_scalar, stop);
+    }
+    if (launch(k, 1)) return 1;
+    const buffer &b = ctx->buffers[k->output_keys.back()];
+    gfhip::launch_max_reduce(b.pointer, k->num_rays, k->item.dtype == GFIR_F64, ctx->device_scalar,
+                             ctx->num_cus, ctx->stream);
+    GFHIP_TRY(ctx, hipGetLastError(), "max_reduce launch");
+    return 0;
+}
+
 extern "C" int gfhip_run_max(gfhip_kernel *k, double *max_value) {
     if (!k) return 1;
     gfhip_context *ctx = k->ctx;
     GFHIP_TRY(ctx, hipSetDevice(ctx->device), "hipSetDevice");
     if (k->output_keys.empty()) return ctx->fail("converge item has no output to reduce");
-    if (launch(k, 1)) return 1;
-    const buffer &b = ctx->buffers[k->output_keys.back()];
     GFHIP_TRY(ctx, hipMemsetAsync(ctx->device_scalar, 0, sizeof(unsigned long long), ctx->stream), "hipMemsetAsync");
-    gfhip::launch_max_reduce(b.pointer, k->num_rays, k->item.dtype == GFIR_F64, ctx->device_scalar,
-                             ctx->num_cus, ctx->stream);
-    GFHIP_TRY(ctx, hipGetLastError(), "max_reduce launch");
+    if (enqueue_pass_with_max(k, nullptr)) return 1;
     GFHIP_TRY(ctx, hipMemcpyAsync(ctx->host_scalar, ctx->device_scalar, sizeof(unsigned long long),
                                   hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
     GFHIP_TRY(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
@@ -491,7 +558,8 @@ extern "C" int gfhip_run_max(gfhip_kernel *k, double *max_value) {
     return 0;
 }
 
-//  workflow::converge_item::run, workflow.hpp:179-205, in the item's own type.
+//  workflow::converge_item::run, workflow.hpp:179-205, in the item's own type, one host
+//  synchronisation per pass: the form for items without `<name>_max` and for empty ensembles.
 template<typename T>
 static int converge_loop(gfhip_kernel *k, const double tolerance_, const size_t max_iterations,
                          size_t *iterations_out, double *last_max) {
@@ -515,34 +583,71 @@ static int converge_loop(gfhip_kernel *k, const double tolerance_, const size_t 
     }
     if (iterations_out) *iterations_out = iterations;
     if (last_max) *last_max = static_cast<double> (max_residual);
-    if (iterations > max_iterations) {
-//  Same report as workflow.hpp:197-204.
-        std::fprintf(stderr, "Workitem failed to converge with in given iterations.\nMinimum residual reached: %g\n",
-                     static_cast<double> (max_residual));
+    return 0;
+}
+
+//  The same loop with its test on the device (reduce.hip: converge_decide_kernel): passes are
+//  enqueued ahead of the host in growing batches, each followed by the one-thread test; once
+//  the test has come out false the passes still queued return at once (`stop`), so exactly the
+//  passes of the host loop run, with the same iteration count — and the host synchronises once
+//  per batch (twice for the benchmark's 25 passes) instead of once per pass.
+static int converge_on_device(gfhip_kernel *k, const double tolerance, const size_t max_iterations,
+                              size_t *iterations_out, double *last_max) {
+    gfhip_context *ctx = k->ctx;
+    const bool f64 = k->item.dtype == GFIR_F64;
+    gfhip::converge_state &host = *ctx->host_converge;
+    host = gfhip::converge_state();
+    host.last = host.off_last = f64 ? std::numeric_limits<double>::max()
+                                    : static_cast<double> (std::numeric_limits<float>::max());
+    host.tolerance = tolerance;
+    host.limit = max_iterations;
+    GFHIP_TRY(ctx, hipMemcpyAsync(ctx->device_converge, &host, sizeof(host), hipMemcpyHostToDevice, ctx->stream),
+              "hipMemcpyAsync(converge state)");
+    GFHIP_TRY(ctx, hipMemsetAsync(ctx->device_scalar, 0, sizeof(unsigned long long), ctx->stream), "hipMemsetAsync");
+    GFHIP_TRY(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");     // `host` is written again below
+    const unsigned int *stop = &ctx->device_converge->done;
+    size_t batch = 16;
+    for (;;) {
+        for (size_t p = 0; p < batch; p++) {
+            if (enqueue_pass_with_max(k, stop)) return 1;
+            gfhip::launch_converge_decide(f64, ctx->device_scalar, ctx->device_converge, ctx->stream);
+            GFHIP_TRY(ctx, hipGetLastError(), "converge_decide launch");
+        }
+        GFHIP_TRY(ctx, hipMemcpyAsync(&host, ctx->device_converge, sizeof(host), hipMemcpyDeviceToHost, ctx->stream),
+                  "hipMemcpyAsync(converge state)");
+        GFHIP_TRY(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+        if (host.done) break;
+        if (batch < 64) batch *= 2;
     }
+    if (iterations_out) *iterations_out = static_cast<size_t> (host.iterations);
+    if (last_max) *last_max = host.max_residual;
     return 0;
 }
 
 extern "C" int gfhip_converge(gfhip_kernel *k, double tolerance, size_t max_iterations,
                               size_t *iterations, double *last_max) {
     if (!k) return 1;
-    if (k->item.dtype == GFIR_F64) {
-        return converge_loop<double> (k, tolerance, max_iterations, iterations, last_max);
+    gfhip_context *ctx = k->ctx;
+    GFHIP_TRY(ctx, hipSetDevice(ctx->device), "hipSetDevice");
+    if (k->output_keys.empty()) return ctx->fail("converge item has no output to reduce");
+    if (!k->built) return ctx->fail("kernel has not been compiled (gfhip_compile)");
+    if (!k->bound) return ctx->fail("kernel arguments are not bound (gfhip_create_kernel_call)");
+    size_t used = 0;
+    double residual = 0.0;
+    int status;
+    if (k->max_function && k->num_rays > 0) {
+        status = converge_on_device(k, tolerance, max_iterations, &used, &residual);
+    } else if (k->item.dtype == GFIR_F64) {
+        status = converge_loop<double> (k, tolerance, max_iterations, &used, &residual);
+    } else {
+        status = converge_loop<float> (k, tolerance, max_iterations, &used, &residual);
     }
-    return converge_loop<float> (k, tolerance, max_iterations, iterations, last_max);
-}
-
-//  After a drain: did any lane leave the window in which the shared-reciprocal division is
-//  the IEEE one?  Reported once, loudly; the data is still returned.
-static int check_flags(gfhip_context *ctx) {
-    unsigned int flags = 0;
-    GFHIP_TRY(ctx, hipMemcpy(&flags, ctx->device_flags, sizeof(flags), hipMemcpyDeviceToHost), "hipMemcpy(flags)");
-    if ((flags & 1u) && !ctx->flags_reported) {
-        ctx->flags_reported = true;
-        std::fprintf(stderr, "graph_framework_amd: a denominator left the window in which the shared-reciprocal "
-                             "division is the IEEE sequence ([2^-500, 2^500] fp64, [2^-100, 2^100] fp32) or a "
-                             "result is not finite; quotients are no longer guaranteed bit-identical to IEEE "
-                             "division.  Rebuild with GFHIP_DIVISION=ieee for the exact sequence.\n");
+    if (status) return status;
+    if (iterations) *iterations = used;
+    if (last_max) *last_max = residual;
+    if (used > max_iterations) {
+//  Same report as workflow.hpp:197-204.
+        std::fprintf(stderr, "Workitem failed to converge with in given iterations.\nMinimum residual reached: %g\n", residual);
     }
     return 0;
 }
@@ -553,7 +658,7 @@ extern "C" int gfhip_converge_per_ray(gfhip_kernel *k, double tolerance, size_t 
     if (!k) return 1;
     gfhip_context *ctx = k->ctx;
     GFHIP_TRY(ctx, hipSetDevice(ctx->device), "hipSetDevice");
-    if (!k->function) return ctx->fail("kernel has not been compiled (gfhip_compile)");
+    if (!k->built) return ctx->fail("kernel has not been compiled (gfhip_compile)");
     if (!k->converge_function) return ctx->fail("item has no setter/output to converge on");
     if (!k->bound) return ctx->fail("kernel arguments are not bound (gfhip_create_kernel_call)");
     if (k->num_rays == 0) {
@@ -604,8 +709,17 @@ extern "C" int gfhip_converge_per_ray(gfhip_kernel *k, double tolerance, size_t 
 extern "C" int gfhip_wait(gfhip_context *ctx) {
     if (!ctx) return 1;
     GFHIP_TRY(ctx, hipSetDevice(ctx->device), "hipSetDevice");
+//  Host mirrors handed out by gfhip_get_host_buffer hold the device contents as of this drain:
+//  all copies are queued behind the kernels, then ONE synchronisation.
+    for (auto &kv : ctx->buffers) {
+        buffer &b = kv.second;
+        if (b.mirror && b.count) {
+            GFHIP_TRY(ctx, hipMemcpyAsync(b.mirror, b.pointer, b.count*(b.dtype == GFIR_F32 ? 4 : 8),
+                                          hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync(mirror)");
+        }
+    }
     GFHIP_TRY(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
-    return check_flags(ctx);
+    return 0;
 }
 
 extern "C" int gfhip_get_flags(gfhip_context *ctx, unsigned int *flags) {
@@ -674,13 +788,50 @@ extern "C" void *gfhip_get_buffer(gfhip_context *ctx, uint64_t key, size_t *coun
     return b->pointer;
 }
 
+extern "C" int gfhip_allocate_buffer(gfhip_context *ctx, uint64_t key, size_t count, uint32_t dtype) {
+    if (!ctx) return 1;
+    if (dtype != GFIR_F32 && dtype != GFIR_F64) return ctx->fail("bad dtype");
+    GFHIP_TRY(ctx, hipSetDevice(ctx->device), "hipSetDevice");
+    return ensure_buffer(ctx, key, count, dtype, nullptr);
+}
+
+extern "C" int gfhip_get_buffer_info(gfhip_context *ctx, uint64_t key, size_t *count, uint32_t *dtype) {
+    if (!ctx) return 1;
+    buffer *b = find_buffer(ctx, key);
+    if (!b) return 1;
+    if (count) *count = b->count;
+    if (dtype) *dtype = b->dtype;
+    return 0;
+}
+
+extern "C" void *gfhip_get_host_buffer(gfhip_context *ctx, uint64_t key, size_t *count) {
+    if (!ctx) return nullptr;
+    buffer *b = find_buffer(ctx, key);
+    if (!b) return nullptr;
+    if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+    const size_t bytes = b->count*(b->dtype == GFIR_F32 ? 4 : 8);
+    if (!b->mirror) {
+        if (ctx->check(hipHostMalloc(&b->mirror, bytes ? bytes : 8, hipHostMallocDefault), "hipHostMalloc(mirror)")) {
+            b->mirror = nullptr;
+            return nullptr;
+        }
+        if (ctx->check(hipMemcpyAsync(b->mirror, b->pointer, bytes, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync(mirror)") ||
+            ctx->check(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize")) {
+            return nullptr;
+        }
+    }
+    if (count) *count = b->count;
+    return b->mirror;
+}
+
 extern "C" int gfhip_set_buffer(gfhip_context *ctx, uint64_t key, void *device_pointer, size_t count, uint32_t dtype) {
     if (!ctx) return 1;
     if (!device_pointer && count) return ctx->fail("null device pointer");
     if (dtype != GFIR_F32 && dtype != GFIR_F64) return ctx->fail("bad dtype");
     auto found = ctx->buffers.find(key);
-    if (found != ctx->buffers.end() && found->second.owned && found->second.pointer) {
-        (void)hipFree(found->second.pointer);
+    if (found != ctx->buffers.end()) {
+        if (found->second.owned && found->second.pointer) (void)hipFree(found->second.pointer);
+        if (found->second.mirror) (void)hipHostFree(found->second.mirror);
     }
     buffer b;
     b.pointer = device_pointer;
@@ -723,14 +874,25 @@ extern "C" int gfhip_kernel_timing(gfhip_kernel *k, double *average_ms, uint64_t
     GFHIP_TRY(ctx, hipSetDevice(ctx->device), "hipSetDevice");
     GFHIP_TRY(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
     double total = 0.0;
+    k->samples.clear();
     for (auto &e : k->events) {
         float ms = 0.0f;
         GFHIP_TRY(ctx, hipEventElapsedTime(&ms, e.first, e.second), "hipEventElapsedTime");
         total += ms;
+        k->samples.push_back(ms);
         k->free_events.push_back(e);
     }
     if (launches) *launches = k->events.size();
     if (average_ms) *average_ms = k->events.empty() ? 0.0 : total/static_cast<double> (k->events.size());
     k->events.clear();
+    return 0;
+}
+
+extern "C" int gfhip_kernel_timing_samples(gfhip_kernel *k, double *ms, size_t capacity, size_t *count) {
+    if (!k) return 1;
+    if (!k->events.empty() && gfhip_kernel_timing(k, nullptr, nullptr)) return 1;
+    const size_t n = k->samples.size() < capacity ? k->samples.size() : capacity;
+    if (ms && n) std::memcpy(ms, k->samples.data(), n*sizeof(double));
+    if (count) *count = k->samples.size();
     return 0;
 }

@@ -5,6 +5,7 @@
 #ifndef gfir_item_hpp
 #define gfir_item_hpp
 
+#include <cctype>
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -27,8 +28,6 @@ struct item {
     std::vector<gfir_instruction> code;
     std::vector<uint32_t> outputs;
     std::vector<gfir_setter> setters;
-    std::vector<uint32_t> fences;           ///< lowering hint (schedule.hpp): no instruction may be moved across the
-                                            ///< start of these records by the compiler's scheduler
 
     size_t element_size() const {
         return dtype == GFIR_F32 ? 4 : 8;
@@ -77,6 +76,17 @@ struct item {
         std::vector<char> text(h.name_bytes + 1, '\0');
         if (!take(text.data(), h.name_bytes)) return false;
         name = text.data();
+//  The name becomes the kernel's identifier in the generated source.
+        if (name.empty() || name.size() > 63 || !(std::isalpha(static_cast<unsigned char> (name[0])) || name[0] == '_')) {
+            error = "GFIR item name is not an identifier";
+            return false;
+        }
+        for (const char ch : name) {
+            if (!(std::isalnum(static_cast<unsigned char> (ch)) || ch == '_')) {
+                error = "GFIR item name is not an identifier";
+                return false;
+            }
+        }
 
         symbols.clear();
         for (uint32_t i = 0; i < h.num_inputs; i++) {

@@ -32,7 +32,7 @@ struct park_plan {
 //  LDS slot (`park[slot*block + lane]`, conflict free, LDS pipe instead of VALU) and read
 //  back at the first use of every later cluster.  Pure data movement: bits unchanged.
 inline std::vector<park_plan> plan_parking(const item &it, const codegen_options &opt, const size_t lds_used,
-                                           const size_t esize, const uint32_t elements, uint32_t &park_slots) {
+                                           const size_t esize, uint32_t &park_slots) {
     const size_t node_count = it.code.size();
     std::vector<park_plan> plan(node_count);
     park_slots = 0;
@@ -42,7 +42,7 @@ inline std::vector<park_plan> plan_parking(const item &it, const codegen_options
     const uint32_t slot_limit = lds_used < lds_capacity
                               ? static_cast<uint32_t> (std::min<size_t> (opt.park_max_slots, (lds_capacity - lds_used)/slot_bytes))
                               : 0;
-    if (opt.park_in_lds && slot_limit > 0 && elements == 1) {
+    if (opt.park_in_lds && slot_limit > 0) {
         std::vector<std::vector<size_t>> uses(node_count);
         auto arity = [] (const uint32_t op) -> int {
             switch (op) {

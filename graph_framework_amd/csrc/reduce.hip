@@ -15,6 +15,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "converge_state.hpp"
+
 namespace gfhip {
 
 //  Monotone map real -> unsigned so that integer max == floating max.
@@ -78,6 +80,54 @@ max_reduce_kernel(const T *__restrict__ base, const unsigned long long total, co
             block = wave_max[w] > block ? wave_max[w] : block;
         }
         atomicMax(result, ordered(block));
+    }
+}
+
+//  Device side of workflow::converge_item::run (workflow.hpp:179-205): one thread applies the
+//  loop's test to the max the pass has just reduced, in the item's own precision, and either
+//  stops the loop (`done`; later passes of the batch return at once) or advances its state.
+//      while (|max| > tol && |last - max| > tol && |off_last - max| > tol && iterations++ < limit) {
+//          last = max;  if (!(iterations%2)) off_last = max;  max = run_max(); }
+
+template<typename T>
+__global__ void converge_decide_kernel(unsigned long long *__restrict__ reduced, converge_state *__restrict__ state) {
+    if (state->done) return;
+    const unsigned long long key = *reduced;
+    *reduced = 0ull;                                   // ready for the next pass's atomicMax
+    T value;
+    if (sizeof(T) == 8) {
+        const unsigned long long bits = (key >> 63) ? (key & 0x7FFFFFFFFFFFFFFFull) : ~key;
+        value = static_cast<T> (__longlong_as_double(static_cast<long long> (bits)));
+    } else {
+        const unsigned int k32 = static_cast<unsigned int> (key);
+        const unsigned int bits = (k32 >> 31) ? (k32 & 0x7FFFFFFFu) : ~k32;
+        value = static_cast<T> (__uint_as_float(bits));
+    }
+    const T tolerance = static_cast<T> (state->tolerance);
+    const T last = static_cast<T> (state->last), off_last = static_cast<T> (state->off_last);
+    state->max_residual = static_cast<double> (value);
+    state->passes++;
+    const T zero = static_cast<T> (0);
+    const T a = value < zero ? -value : value, t = tolerance < zero ? -tolerance : tolerance;
+    const T dl = last - value, dol = off_last - value;
+    bool go = a > t && (dl < zero ? -dl : dl) > t && (dol < zero ? -dol : dol) > t;
+    if (go) {
+        go = state->iterations < state->limit;
+        state->iterations++;
+    }
+    if (go) {
+        state->last = static_cast<double> (value);
+        if (!(state->iterations%2ull)) state->off_last = static_cast<double> (value);
+    } else {
+        state->done = 1u;
+    }
+}
+
+void launch_converge_decide(const bool f64, unsigned long long *reduced, void *state, hipStream_t stream) {
+    if (f64) {
+        hipLaunchKernelGGL(converge_decide_kernel<double>, dim3(1), dim3(1), 0, stream, reduced, static_cast<converge_state *> (state));
+    } else {
+        hipLaunchKernelGGL(converge_decide_kernel<float>, dim3(1), dim3(1), 0, stream, reduced, static_cast<converge_state *> (state));
     }
 }
 

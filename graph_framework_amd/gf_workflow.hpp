@@ -92,7 +92,7 @@ public:
             init.push_back(found == initial.end() ? nullptr : found->second);
         }
         for (auto &name : outputs) out_keys.push_back(key_of(name));
-        if (gfhip_create_kernel_call(kernel, in_keys.data(), init.data(), out_keys.data())) fail("gfhip_create_kernel_call");
+        if (gfhip_create_kernel_call(kernel, in_keys.data(), init.data(), nullptr, out_keys.data())) fail("gfhip_create_kernel_call");
     }
 
 ///  work_item::run (workflow.hpp:63-65).

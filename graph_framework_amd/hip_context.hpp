@@ -22,6 +22,7 @@
 #ifndef hip_context_h
 #define hip_context_h
 
+#include <algorithm>
 #include <cstdlib>
 #include <functional>
 #include <iostream>
@@ -57,11 +58,17 @@ namespace gpu {
             std::vector<uint8_t> gfir;
         };
         std::vector<pending_item> pending;
-        std::map<std::string, gfhip_kernel *> kernels;
-///  Kernel whose last output is a node (for create_max_call).
+///  What the kernel really takes, after the de-duplication the reference's prefix/postfix do
+///  (each node is bound once, cuda_context.hpp:330-383; an output that is a variable, that equals
+///  a setter's expression or that was listed before is not stored again, cpu_context.hpp:551-553).
+        struct bound_kernel {
+            gfhip_kernel *kernel;
+            graph::input_nodes<T, SAFE_MATH> inputs;        ///< distinct input variables, first-seen order
+            graph::output_nodes<T, SAFE_MATH> outputs;      ///< outputs the kernel stores
+        };
+        std::map<std::string, bound_kernel> kernels;
+///  Kernel whose last stored output is a node (for create_max_call).
         std::map<graph::leaf_node<T, SAFE_MATH> *, gfhip_kernel *> reductions;
-///  Host mirrors handed out by get_buffer, refreshed in wait().
-        std::map<graph::leaf_node<T, SAFE_MATH> *, std::vector<T>> host_buffers;
 
         static uint64_t key(graph::leaf_node<T, SAFE_MATH> *node) {
             return static_cast<uint64_t> (reinterpret_cast<uintptr_t> (node));
@@ -154,7 +161,11 @@ namespace gpu {
             }
             pending_item item;
             item.name = name;
-            item.inputs = inputs;
+            for (auto &input : inputs) {
+                if (std::find(item.inputs.begin(), item.inputs.end(), input) == item.inputs.end()) {
+                    item.inputs.push_back(input);
+                }
+            }
             item.outputs = outputs;
             item.size = size;
             pending.push_back(item);
@@ -174,8 +185,28 @@ namespace gpu {
             source_buffer << "// end kernel" << std::endl;
             if constexpr (!jit::complex_scalar<T>) {
                 pending_item &item = pending.back();
+//  The stores the reference's postfix would emit (cpu_context.hpp:522-580): setters whose
+//  expression is not the variable itself, then outputs that are neither variables nor already
+//  stored by a setter or an earlier output.
+                graph::map_nodes<T, SAFE_MATH> stores;
+                std::vector<graph::leaf_node<T, SAFE_MATH> *> stored;
+                for (auto &[out, in] : setters) {
+                    if (!out->is_match(in)) {
+                        stores.push_back({out, in});
+                        stored.push_back(out.get());
+                    }
+                }
+                graph::output_nodes<T, SAFE_MATH> kept;
+                for (auto &out : item.outputs) {
+                    if (!graph::variable_cast(out).get() &&
+                        std::find(stored.begin(), stored.end(), out.get()) == stored.end()) {
+                        kept.push_back(out);
+                        stored.push_back(out.get());
+                    }
+                }
                 gfir::serializer<T, SAFE_MATH> serialize;
-                item.gfir = serialize(item.name, item.inputs, item.outputs, setters);
+                item.gfir = serialize(item.name, item.inputs, kept, stores);
+                kernels[item.name] = bound_kernel{nullptr, item.inputs, kept};
             }
         }
 
@@ -202,7 +233,7 @@ namespace gpu {
                 if (!kernel) {
                     check(1, "gfhip_add_kernel");
                 }
-                kernels[item.name] = kernel;
+                kernels[item.name].kernel = kernel;
             }
             pending.clear();
             check(gfhip_compile(context), "gfhip_compile");
@@ -221,26 +252,39 @@ namespace gpu {
                                                      const size_t num_rays,
                                                      const jit::texture1d_list &tex1d_list,
                                                      const jit::texture2d_list &tex2d_list) {
-            (void)state; (void)num_rays; (void)tex1d_list; (void)tex2d_list;
-            gfhip_kernel *kernel = kernels.at(kernel_name);
+            (void)state; (void)inputs; (void)tex1d_list; (void)tex2d_list;
+            auto found = kernels.find(kernel_name);
+            if (found == kernels.end() || !found->second.kernel) {
+                std::cerr << "hip_context: kernel " << kernel_name << " was not added and compiled." << std::endl;
+                exit(-1);
+            }
+            bound_kernel &bound = found->second;
+            gfhip_kernel *kernel = bound.kernel;
 
             std::vector<uint64_t> input_keys, output_keys;
             std::vector<backend::buffer<T>> initial;
             std::vector<const void *> initial_pointers;
-            for (auto &input : inputs) {
+            std::vector<size_t> initial_counts;
+            for (auto &input : bound.inputs) {
                 input_keys.push_back(key(input.get()));
                 initial.push_back(input->evaluate());
             }
             for (auto &buffer : initial) {
                 initial_pointers.push_back(buffer.data());
+                initial_counts.push_back(buffer.size());
             }
-            for (auto &output : outputs) {
+            for (auto &output : bound.outputs) {
                 output_keys.push_back(key(output.get()));
             }
-            check(gfhip_create_kernel_call(kernel, input_keys.data(), initial_pointers.data(),
+            check(gfhip_create_kernel_call(kernel, input_keys.data(), initial_pointers.data(), initial_counts.data(),
                                            output_keys.data()), "gfhip_create_kernel_call");
-            if (!outputs.empty()) {
-                reductions[outputs.back().get()] = kernel;
+//  Every listed node gets its buffer on first sight, stored by this kernel or not.
+            const uint32_t dtype = std::is_same<T, float>::value ? GFIR_F32 : GFIR_F64;
+            for (auto &output : outputs) {
+                check(gfhip_allocate_buffer(context, key(output.get()), num_rays, dtype), "gfhip_allocate_buffer");
+            }
+            if (!bound.outputs.empty()) {
+                reductions[bound.outputs.back().get()] = kernel;
             }
 
             return [this, kernel] () mutable {
@@ -254,7 +298,12 @@ namespace gpu {
         std::function<T(void)> create_max_call(graph::shared_leaf<T, SAFE_MATH> &argument,
                                                std::function<void(void)> run) {
             (void)run;
-            gfhip_kernel *kernel = reductions.at(argument.get());
+            auto found = reductions.find(argument.get());
+            if (found == reductions.end()) {
+                std::cerr << "hip_context: create_max_call needs the last stored output of a kernel." << std::endl;
+                exit(-1);
+            }
+            gfhip_kernel *kernel = found->second;
             return [this, kernel] () mutable {
                 double value;
                 check(gfhip_run_max(kernel, &value), "gfhip_run_max");
@@ -267,9 +316,6 @@ namespace gpu {
 //------------------------------------------------------------------------------
         void wait() {
             check(gfhip_wait(context), "gfhip_wait");
-            for (auto &[node, buffer] : host_buffers) {
-                check(gfhip_copy_to_host(context, key(node), buffer.data()), "gfhip_copy_to_host");
-            }
         }
 
 //------------------------------------------------------------------------------
@@ -312,20 +358,15 @@ namespace gpu {
 //------------------------------------------------------------------------------
 ///  @brief Get a stable host-readable buffer for a node (output.hpp:271).
 ///
-///  The pointer stays valid for the life of the context and holds the device
-///  contents as of the last wait().
+///  A pinned host mirror owned by the library: the pointer stays valid for the life of
+///  the context and holds the device contents as of the last wait().
 //------------------------------------------------------------------------------
         T *get_buffer(graph::shared_leaf<T, SAFE_MATH> &node) {
-            auto found = host_buffers.find(node.get());
-            if (found == host_buffers.end()) {
-                size_t count = 0;
-                if (!gfhip_get_buffer(context, key(node.get()), &count)) {
-                    check(1, "gfhip_get_buffer");
-                }
-                found = host_buffers.insert({node.get(), std::vector<T> (count)}).first;
-                check(gfhip_copy_to_host(context, key(node.get()), found->second.data()), "gfhip_copy_to_host");
+            void *mirror = gfhip_get_host_buffer(context, key(node.get()), nullptr);
+            if (!mirror) {
+                check(1, "gfhip_get_host_buffer");
             }
-            return found->second.data();
+            return static_cast<T *> (mirror);
         }
     };
 }

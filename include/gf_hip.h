@@ -71,27 +71,32 @@ int gfhip_compile(gfhip_context *ctx);
 
 /* Bind the kernel's arguments to buffers.  input_keys[i] / output_keys[o] name
  * the buffers; on first sight of a key the buffer is allocated with num_rays
- * elements and, for inputs with a non-NULL input_init[i], filled from that host
- * array.  Replaces  create_kernel_call(name, inputs, outputs, state, num_rays, ...)
- * (cuda_context.hpp:316-531, cpu_context.hpp:233-298). */
+ * elements (zero-filled) and, for inputs with a non-NULL input_init[i], its first
+ * input_counts[i] elements (num_rays if input_counts is NULL) are filled from
+ * that host array.  Replaces  create_kernel_call(name, inputs, outputs, state,
+ * num_rays, ...)  (cuda_context.hpp:316-531, cpu_context.hpp:233-298). */
 int gfhip_create_kernel_call(gfhip_kernel *kernel,
                              const uint64_t *input_keys, const void *const *input_init,
-                             const uint64_t *output_keys);
+                             const size_t *input_counts, const uint64_t *output_keys);
 
 /* Asynchronous launch of the kernel on the context's stream (the closure
  * create_kernel_call returns in the reference).  `steps` > 1 repeats the item
  * inside one launch, keeping the state in registers between passes. */
 int gfhip_run(gfhip_kernel *kernel, uint32_t steps);
 
-/* Run the kernel, reduce max over its LAST output buffer on the device,
- * synchronise and return the scalar.  Replaces  create_max_call(arg, run)
- * (cuda_context.hpp:540-576, cpu_context.hpp:306-322). */
+/* Run the kernel, reduce max over its LAST output on the device, synchronise and
+ * return the scalar.  Items of up to 1500 nodes reduce inside the launch
+ * (`<name>_max`: wave shuffle + one atomic per workgroup); larger ones run the
+ * separate reduction kernel over the output buffer.  Replaces
+ * create_max_call(arg, run)  (cuda_context.hpp:540-576, cpu_context.hpp:306-322). */
 int gfhip_run_max(gfhip_kernel *kernel, double *max_value);
 
-/* The host loop of workflow::converge_item::run (workflow.hpp:179-205) around
+/* The loop of workflow::converge_item::run (workflow.hpp:179-205) around
  * gfhip_run_max: repeat until |max| <= tol, or max stalls against the previous
- * or the previous-but-one value, or max_iterations.  Results are identical to
- * calling gfhip_run_max from that loop. */
+ * or the previous-but-one value, or max_iterations.  The loop's test runs on the
+ * device after each pass and passes are queued ahead of the host, so the host
+ * synchronises once per batch of passes; the passes that run, the iteration
+ * count and the results are identical to calling gfhip_run_max from that loop. */
 int gfhip_converge(gfhip_kernel *kernel, double tolerance, size_t max_iterations,
                    size_t *iterations, double *last_max);
 
@@ -108,9 +113,10 @@ int gfhip_converge_per_ray(gfhip_kernel *kernel, double tolerance, size_t max_it
 int gfhip_wait(gfhip_context *ctx);
 
 /* Status bits raised by kernels since the context was created (after a drain).
- * Bit 0: a lane's denominator left [2^-500, 2^500] (fp64) / [2^-100, 2^100] (fp32), or a result was not finite, so
- * the shared-reciprocal division is no longer guaranteed bit-identical to IEEE division
- * for that lane; gfhip_wait() also reports this once on stderr. */
+ * Bit 0 (informational): some lane failed a check of the shared-reciprocal
+ * division (a denominator outside [2^-500, 2^500] fp64 / [2^-100, 2^100] fp32,
+ * a non-finite result or gather argument, a stored zero that came from a
+ * quotient) and redid its pass with the compiler's IEEE division. */
 int gfhip_get_flags(gfhip_context *ctx, unsigned int *flags);
 
 /* Whole-buffer copies, synchronous on return.  Replace copy_to_device /
@@ -127,6 +133,23 @@ int gfhip_check_value(gfhip_context *ctx, uint64_t key, size_t index, double *va
  * The reference's get_buffer (cuda_context.hpp:650-652) returns the managed
  * pointer; here it is device memory. */
 void *gfhip_get_buffer(gfhip_context *ctx, uint64_t key, size_t *count);
+
+/* Allocate (zero-filled) the buffer for `key` if it does not exist yet: the
+ * buffer side of create_kernel_call for nodes the kernel itself never stores
+ * (an output that is a variable or equals a setter's expression,
+ * cpu_context.hpp:551-553, still gets its buffer at cuda_context.hpp:364-383). */
+int gfhip_allocate_buffer(gfhip_context *ctx, uint64_t key, size_t count, uint32_t dtype);
+
+/* Element count and dtype (enum gfir_dtype) of a buffer; non-zero if the key is unknown. */
+int gfhip_get_buffer_info(gfhip_context *ctx, uint64_t key, size_t *count, uint32_t *dtype);
+
+/* A stable, pinned HOST copy of the buffer for `key`, valid for the life of the
+ * context and refreshed by every gfhip_wait() (all mirrors are copied behind
+ * the queued kernels, then one synchronisation).  This is what the reference's
+ *   T *get_buffer(node)   (jit.hpp:336, cuda_context.hpp:1002-1004; managed
+ * memory there) means to its caller output.hpp:271: a pointer the NetCDF
+ * writer thread reads after wait(). */
+void *gfhip_get_host_buffer(gfhip_context *ctx, uint64_t key, size_t *count);
 
 /* Adopt caller-owned device memory (e.g. a shard of a larger allocation) as the
  * buffer for `key`; the context will not free it. */
@@ -158,6 +181,10 @@ void gfhip_free_string(char *text);
  * roofline line. */
 int gfhip_enable_timing(gfhip_context *ctx, int enable);
 int gfhip_kernel_timing(gfhip_kernel *kernel, double *average_ms, uint64_t *launches);
+/* The individual durations (ms, launch order) behind the last gfhip_kernel_timing
+ * (which this call performs first if launches are pending): up to `capacity`
+ * values into `ms`, the number available into `count`. */
+int gfhip_kernel_timing_samples(gfhip_kernel *kernel, double *ms, size_t capacity, size_t *count);
 
 #ifdef __cplusplus
 }

@@ -139,6 +139,9 @@ void run_type(const char *label, const T loose) {
     const std::vector<T> w = list<T> ({1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 7.0, 8.0, 9.0, 10.0});
     run_case<T> ("a + b, a - b, a*b, a/b", {a, b}, {u, v}, {a + b, a - b, a*b, a/b}, {});
     run_case<T> ("fma(a, b, c), (a + b)*c - a/c", {a, b, c}, {u, v, w}, {graph::fma(a, b, c), (a + b)*c - a/c}, {});
+//  Work items the reference accepts and binds once per node (cuda_context.hpp:330-383,
+//  cpu_context.hpp:551-553): an output that is itself an input variable, the same output twice.
+    run_case<T> ("outputs {a, a*b, a*b, a + b}: a variable and a repeated output", {a, b}, {u, v}, {a, a*b, a*b, a + b}, {});
     run_case<T> ("a^2, a^3, a^5, sqrt(a*a + 1)", {a}, {u}, {graph::pow(a, 2.0), graph::pow(a, 3.0), graph::pow(a, 5.0), graph::sqrt(a*a + 1.0)}, {});
     run_case<T> ("many quotients of one denominator", {a, b, c}, {u, v, w},
                  {a/(c*c + 1.0) + b/(c*c + 1.0) + (a*b)/(c*c + 1.0), (a - b)/(c*c + 1.0), c/(a*a + b*b)}, {});

@@ -145,6 +145,13 @@ def random_item(seed, dtype="f64", num_inputs=6, num_nodes=400, num_outputs=3, n
             v = b.squash(v)
         setters.append((v, int(target)))
 
+    return serialize(b, outputs, setters, num_inputs, name), len(b.code)
+
+
+def serialize(b, outputs, setters, num_inputs, name):
+    """GFIR bytes (include/gfir.h) of a Builder's records with the given output nodes and
+    (value node, input index) setters."""
+    dtype = b.dtype
     name_bytes = name.encode() + b"\0"*(4 - len(name) % 4)
     blob = struct.pack("<8s8I", b"GFIR0001", 1 if dtype == "f64" else 0, num_inputs, len(outputs), len(setters),
                        len(b.tables), len(b.code), len(name_bytes), 0)
@@ -160,4 +167,26 @@ def random_item(seed, dtype="f64", num_inputs=6, num_nodes=400, num_outputs=3, n
     blob += struct.pack("<%dI" % len(outputs), *outputs)
     for value, target in setters:
         blob += struct.pack("<II", value, target)
-    return blob, len(b.code)
+    return blob
+
+
+def division_stress_item(dtype="f64", name="division_stress"):
+    """A hand-made item around the corner cases of division: inputs n0, n1, d0, d1, x;
+    quotients that share a denominator, a quotient used as a denominator, as a gather argument
+    and under a square root; outputs and a setter that store quotients (and so may store a zero)."""
+    rng = np.random.default_rng(5)
+    b = Builder(rng, dtype, 5)
+    n0, n1, d0, d1, x = b.inputs
+    q0 = b.emit(DIV, n0, d0)
+    q1 = b.emit(DIV, n1, d0)                               # shares d0's reciprocal
+    q2 = b.emit(DIV, b.emit(MUL, n0, n1), d1)
+    q3 = b.emit(DIV, x, b.emit(ADD, q0, b.constant(2.0)))  # a quotient inside a denominator
+    table = b.table(1, 16)
+    g = b.emit(GATHER1, q1, aux=table, imm=(float(b.real(0.25)), float(b.real(-2.0)), 0.0, 0.0))   # a quotient as gather argument
+    table2 = b.table(5, 6)
+    g2 = b.emit(GATHER2, q0, q2, aux=table2, imm=(float(b.real(0.5)), float(b.real(-1.0)), float(b.real(0.5)), float(b.real(-1.0))))
+    s = b.emit(SQRT, b.emit(MUL, q0, q0))
+    mix = b.emit(FMA, g, q3, b.emit(MUL, g2, s))
+    outputs = [q0, q1, q2, q3, mix]
+    setters = [(b.emit(DIV, x, d1), 4)]                    # x <- x/d1
+    return serialize(b, outputs, setters, 5, name)

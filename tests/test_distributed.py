@@ -68,3 +68,48 @@ def test_broadcast_and_all_gather_world_size_2(total):
         assert p.exitcode == 0
     for rank, same, gathered_ok, slowest in results:
         assert same and gathered_ok and slowest == 2.0
+
+
+def _run_bench(arguments, env=None, timeout=300):
+    import subprocess
+    environment = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    environment.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + arguments, env=environment,
+                          capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus N` without a launcher becomes the launcher (the reference's
+    benchmark needs none: one thread per device, xrays_bench.cpp:34-108): N fresh rank processes,
+    rendezvous on 127.0.0.1, stdout = rank 0's ONE JSON line.  Driven here through the CPU
+    rehearsal of the rank-side plumbing (gloo): item broadcast, reference shard split,
+    all-gather of unequal shards, max over ranks."""
+    import json
+    out = _run_bench(["--gpus", "3", "--rehearse-cpu", "--total-rays", "1000003"])
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 3 and line["total_rays"] == 1000003 and line["launcher"] == "bench.py"
+    assert line["gathered_elements"] == 8*1000003 and line["slowest_rank"] == 2.0 and line["item_bytes"] > 100000
+
+
+def test_bench_launcher_reports_a_failed_rank():
+    """Any rank failing makes the launcher stop the others (by PID) and exit non-zero."""
+    out = _run_bench(["--gpus", "2", "--rehearse-cpu", "--fail-rank", "1"])
+    assert out.returncode != 0
+    assert "rank 1 failed" in out.stderr
+
+
+def test_bench_rank_under_an_external_launcher():
+    """The same rank code under torch.distributed.run (how the round driver starts N > 1)."""
+    import json
+    import subprocess
+    port = _free_port()
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-cpu"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["launcher"] == "torchrun"

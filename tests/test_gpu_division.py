@@ -1,0 +1,107 @@
+"""The division contract of the lowering (graph_framework_amd/csrc/prelude.hpp) at its edges.
+
+The reference divides with the compiler's IEEE `/` (arithmetic.hpp:3508); the lowering shares one
+refined reciprocal per denominator and must still return the IEEE quotient for EVERY operand:
+lanes whose operands leave the window in which the shared sequence is the IEEE one redo their
+pass with the compiler's division.  Checked here bit for bit against the CPU oracle on operands
+the benchmark never sees: denominators of 2^+-600 (fp64) / 2^+-110 (fp32), zero and infinite
+denominators, zero numerators of either sign, infinite and overflowing numerators, and — in the
+`checked` mode, which also tracks every numerator — subnormal and near-subnormal numerators.
+"""
+import numpy as np
+import pytest
+
+import gfir_random
+from oracle import gfir
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return a.view(np.uint64 if a.dtype == np.float64 else np.uint32)
+
+
+def _same(got, want):
+    """Bit equality (the sign of a zero included); NaNs must coincide (payloads may differ
+    between the host's and the device's arithmetic)."""
+    nan = np.isnan(want)
+    return np.array_equal(np.isnan(got), nan) and np.array_equal(_bits(got)[~nan], _bits(want)[~nan])
+
+
+def _operands(dtype, tiny_numerators):
+    real = np.float64 if dtype == "f64" else np.float32
+    big, small = (600, -600) if dtype == "f64" else (110, -110)
+    info = np.finfo(real)
+    denominators = [3.0, -3.0, 2.0**big, -2.0**big, 2.0**small, 2.0**small*1.5, 0.0, -0.0, np.inf, -np.inf,
+                    float(info.max), float(info.tiny), float(info.tiny)/4, 1.0e-30, 7.0e10]
+    numerators = [1.0, -1.0, 0.0, -0.0, 5.5, np.inf, -np.inf, float(info.max), float(info.max)/3, 1.0e-20]
+    if tiny_numerators:
+#  what the default mode does not track (prelude.hpp): non-zero numerators below 2^-969 / 2^-102
+#  and quotients below the normal range
+        numerators += [2.0**small, 1.0e-30, float(info.tiny), float(info.tiny)/8, -float(info.tiny)/1024,
+                       float(np.nextafter(real(0), real(1))),
+                       2.0**(-980 if dtype == "f64" else -105), 3.0*2.0**(-1000 if dtype == "f64" else -120)]
+    with np.errstate(over="ignore", under="ignore"):
+        n0, d0 = np.meshgrid(np.array(numerators, dtype=real), np.array(denominators, dtype=real), indexing="ij")
+    n0, d0 = n0.ravel().copy(), d0.ravel().copy()
+    rng = np.random.default_rng(17)
+#  second numerator / denominator / free input: ordinary values with a sprinkling of the specials
+    n1 = rng.uniform(-2.0, 2.0, n0.size).astype(real)
+    d1 = rng.uniform(0.5, 4.0, n0.size).astype(real)
+    x = rng.uniform(-1.0, 1.0, n0.size).astype(real)
+    n1[::7] = 0.0
+    n1[3::11] = -0.0
+    d1[5::13] = np.array(denominators, dtype=real)[rng.integers(0, len(denominators), d1[5::13].size)]
+    x[2::9] = 0.0
+    return [n0, n1, d0, d1, x]
+
+
+@pytest.mark.parametrize("mode", ["shared", "checked", "ieee"])
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_division_at_the_edges_is_the_ieee_quotient(monkeypatch, tmp_path, dtype, mode):
+    from graph_framework_amd import Context
+    monkeypatch.setenv("GFHIP_DIVISION", mode)
+    monkeypatch.setenv("GFHIP_CACHE_DIR", str(tmp_path))
+    blob = gfir_random.division_stress_item(dtype)
+    oracle_item = gfir.Item(blob)
+    columns = _operands(dtype, tiny_numerators=(mode != "shared"))
+    rays = columns[0].size
+
+    context = Context(0)
+    kernel = context.add_kernel(blob, rays)
+    context.compile()
+    in_keys, out_keys = ["n0", "n1", "d0", "d1", "x"], ["q0", "q1", "q2", "q3", "mix"]
+    kernel.create_kernel_call(in_keys, out_keys, columns)
+    expected = [c.copy() for c in columns]
+    with np.errstate(all="ignore"):
+        for launch_steps in (1, 2):
+            expected_out, _ = oracle_item.run(expected, steps=launch_steps)
+            kernel.run(launch_steps)
+            context.wait()
+            for key, want in zip(in_keys + out_keys, expected + expected_out):
+                got = context.copy_to_host(key, np.empty(rays, dtype=oracle_item.np_dtype))
+                assert _same(got, want), (key, launch_steps, np.flatnonzero(_bits(got) != _bits(want))[:8])
+#  Lanes did leave the window: the status bit says that the second body ran (never in `ieee` mode).
+    assert context.flags() == (0 if mode == "ieee" else 1)
+    context.close()
+
+
+def test_in_window_operands_never_take_the_second_body():
+    """Ordinary operands (the fuzz items' range) must not raise the status bit."""
+    from graph_framework_amd import Context
+    blob = gfir_random.division_stress_item("f64")
+    rng = np.random.default_rng(3)
+    rays = 1000
+    columns = [rng.uniform(0.5, 2.0, rays) for _ in range(5)]
+    context = Context(0)
+    kernel = context.add_kernel(blob, rays)
+    context.compile()
+    kernel.create_kernel_call(["n0", "n1", "d0", "d1", "x"], ["q0", "q1", "q2", "q3", "mix"], columns)
+    kernel.run(3)
+    context.wait()
+    assert context.flags() == 0
+    expected = [c.copy() for c in columns]
+    expected_out, _ = gfir.Item(blob).run(expected, steps=3)
+    for key, want in zip(["x", "q0", "mix"], [expected[4], expected_out[0], expected_out[4]]):
+        assert np.array_equal(context.copy_to_host(key, np.empty(rays)), want), key
+    context.close()

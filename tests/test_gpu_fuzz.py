@@ -54,17 +54,18 @@ def test_random_work_item_bit_exact(seed, dtype, inputs, nodes, outputs, setters
     context.close()
 
 
-def test_packed_pairs_mode_is_bit_exact(monkeypatch):
-    """GFHIP_PACKED=1 (fp32 items: two rays per lane as one float2, v_pk_*_f32 arithmetic; an
-    option, not the default — it is not faster on MI355X) computes the same bits,
-    including an odd ensemble whose last lane owns a single ray."""
+@pytest.mark.parametrize("option,value", [("GFHIP_DIVISION", "checked"), ("GFHIP_DIVISION", "ieee"), ("GFHIP_SCHEDULE", "source"),
+                                          ("GFHIP_PARK", "heavy"), ("GFHIP_LDS_BUDGET", "0"), ("GFHIP_COMPACT_TABLES", "0")])
+def test_alternative_lowerings_are_bit_exact(monkeypatch, tmp_path, option, value):
+    """Every knob options.hpp still offers computes the same bits as the default lowering."""
     from graph_framework_amd import Context
-    monkeypatch.setenv("GFHIP_PACKED", "1")
-    for seed, rays in ((21, 1001), (22, 2)):
-        blob, _ = gfir_random.random_item(seed, "f32", 6, 500, 3, 4)
+    monkeypatch.setenv(option, value)
+    monkeypatch.setenv("GFHIP_CACHE_DIR", str(tmp_path))
+    for seed, dtype, nodes, rays in ((31, "f64", 2200, 777), (32, "f32", 500, 130)):
+        blob, _ = gfir_random.random_item(seed, dtype, 6, nodes, 3, 4)
         oracle_item = gfir.Item(blob)
         rng = np.random.default_rng(seed)
-        initial = [rng.uniform(-1.0, 1.0, rays).astype(np.float32) for _ in range(6)]
+        initial = [rng.uniform(-1.0, 1.0, rays).astype(oracle_item.np_dtype) for _ in range(6)]
         context = Context(0)
         kernel = context.add_kernel(blob, rays)
         context.compile()
@@ -77,6 +78,6 @@ def test_packed_pairs_mode_is_bit_exact(monkeypatch):
             context.wait()
             assert context.flags() == 0
             for key, want in zip(in_keys + out_keys, expected + expected_out):
-                got = context.copy_to_host(key, np.empty(rays, dtype=np.float32))
-                assert np.array_equal(got, want), (key, launch_steps)
+                got = context.copy_to_host(key, np.empty(rays, dtype=oracle_item.np_dtype))
+                assert np.array_equal(got, want), (option, value, key, launch_steps)
         context.close()
