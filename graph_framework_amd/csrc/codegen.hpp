@@ -98,6 +98,7 @@ struct kernel_writer {
 
     const bool f64 = it.dtype == GFIR_F64;
     const bool track_numerators = opt.division == division_mode::checked;
+    const bool fixup = division_fixup(it, opt);
     const char *real = f64 ? "double" : "float";
     const std::string sfx = f64 ? "" : "f";
     const size_t esize = it.element_size();
@@ -144,7 +145,7 @@ struct kernel_writer {
                 const std::string quotient = "x" + std::to_string(quotient_count++);
                 s << "                const real " << quotient << " = gf_div(" << N(arg) << " - " << literal(offset) << ", " << literal(scale) << ", "
                   << literal(f64 ? 1.0/scale : static_cast<double> (1.0f/static_cast<float> (scale))) << ");\n";
-                s << "                finite_check += " << quotient << ";\n";
+                s << "                vmax = __builtin_elementwise_maximum(vmax, gf_magnitude(" << quotient << "));\n";
                 e << quotient;
             } else {
                 e << "(" << N(arg) << " - " << literal(offset) << ")/" << literal(scale);
@@ -296,6 +297,18 @@ struct kernel_writer {
                     s << ind << "const real r" << i << " = " << value << ";\n";
                     break;
                 }
+                case GFIR_INDEX1:
+                case GFIR_INDEX2: {
+//  index_1D/2D_node: an element of an input variable's own buffer, picked by the clamped index
+//  (piecewise.hpp:1530-1575, :1899-1990); a plain global load, no packing.
+                    const bool two = c.op == GFIR_INDEX2;
+                    const std::string first = index_expression(c.a, c.imm[0], c.imm[1], two ? c.reserved : c.aux);
+                    const std::string second = two ? index_expression(c.b, c.imm[2], c.imm[3], c.aux) : std::string();
+                    s << ind << "const real r" << i << " = in" << c.c << "[" << first;
+                    if (two) s << "*" << c.aux << "u + " << second;
+                    s << "];\n";
+                    break;
+                }
                 default:
                     s << ind << "#error unsupported GFIR op\n";
             }
@@ -312,6 +325,34 @@ struct kernel_writer {
         for (size_t o = 0; o < it.outputs.size(); o++) {
             s << ind << "so" << o << " = " << N(it.outputs[o]) << ";\n";
         }
+    }
+
+//  The pass with the compiler's IEEE division, as a function of its own: a lane that failed a
+//  check of the shared-reciprocal body calls it.  Not inlined, so that the kernel's hot path
+//  keeps the register allocation and schedule it has without it (inlined as a second body it
+//  cost the RK4 kernel 4-8 %: spills and 28 B of scratch per lane on the hot path).
+    void ieee_function() {
+        const std::string results = out.kernel_name + "_results";
+        s << "struct " << results << " {";
+        for (size_t k = 0; k < it.setters.size(); k++) s << " real sv" << k << ";";
+        for (size_t o = 0; o < it.outputs.size(); o++) s << " real so" << o << ";";
+        s << " };\n";
+        s << "static __device__ __attribute__((noinline, cold)) " << results << "\n" << out.kernel_name << "_ieee(";
+        for (size_t i = 0; i < it.symbols.size(); i++) s << "const real v" << i << ", ";
+        for (size_t p = 0; p < out.packs.size(); p++) {
+            s << "const real *__restrict__ " << (out.packs[p].in_lds ? "lds" : "pack") << p << ", ";
+        }
+        if (park_slots) s << "park_t *park, park_t *park_read, ";
+        s << "const int) {\n";
+        s << "            " << results << " redo;\n";
+        for (size_t k = 0; k < it.setters.size(); k++) s << "            real sv" << k << ";\n";
+        for (size_t o = 0; o < it.outputs.size(); o++) s << "            real so" << o << ";\n";
+        s << "            {\n";
+        body(false);
+        s << "            }\n";
+        for (size_t k = 0; k < it.setters.size(); k++) s << "            redo.sv" << k << " = sv" << k << ";\n";
+        for (size_t o = 0; o < it.outputs.size(); o++) s << "            redo.so" << o << " = so" << o << ";\n";
+        s << "            return redo;\n}\n\n";
     }
 
     void kernel(const entry which) {
@@ -350,8 +391,8 @@ struct kernel_writer {
         }
     }
 
+//  LDS: the staged packs (copied once per workgroup) and the parking slots.
     void lds_setup() {
-//  LDS staging.
         if (lds_used) {
             s << "    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];\n";
             size_t offset = 0;
@@ -370,7 +411,6 @@ struct kernel_writer {
 //  `park_read` aliases a write through `park` (so no store-to-load forwarding, which would put
 //  the value back in a register) nor that it does not (so a read is never hoisted above an
 //  earlier write).  Not volatile: waits are placed at the first use, not after the read.
-                s << "    typedef __attribute__((address_space(3))) real park_t;\n";
                 s << "    park_t *park = (park_t *)(lds_raw + " << park_offset << ") + threadIdx.x;\n";
                 s << "    park_t *park_read = park;\n";
                 s << "    asm volatile(\"\" : \"+v\"(park));\n";
@@ -422,39 +462,58 @@ struct kernel_writer {
 //  the end of the pass loop.
     void pass(const entry which) {
         if (use_shared) {
-            s << "            bool bad = false;\n";
+            s << "            bool bad = false, zero = false;\n";
             s << "            {\n";
             s << "                float dmax = gf_magnitude(" << literal(1.0) << "), dmin = dmax;   // extreme |denominator| of this pass\n";
-            s << "                real finite_check = " << literal(0.0) << ";\n";
+            s << "                float vmax = dmax;                                   // extreme |stored value|, |index quotient|\n";
             if (track_numerators) s << "                unsigned int nmin = 0xFFFFFFFFu;                    // smallest non-zero |numerator| key\n";
             body(true);
+//  The finite checks run on the same fp32 image as the window check (a non-finite value, or a
+//  double of 2^1017 and more, reads as a float NaN/infinity and fails the comparison): half a
+//  v_maximum3_f32 per value.
             std::vector<std::string> quotient_results;
             for (size_t k = 0; k < it.setters.size(); k++) {
-                s << "                finite_check += sv" << k << ";\n";
+                s << "                vmax = __builtin_elementwise_maximum(vmax, gf_magnitude(sv" << k << "));\n";
                 if (after_division[it.setters[k].value]) quotient_results.push_back("sv" + std::to_string(k));
             }
             for (size_t o = 0; o < it.outputs.size(); o++) {
-                s << "                finite_check += so" << o << ";\n";
+                s << "                vmax = __builtin_elementwise_maximum(vmax, gf_magnitude(so" << o << "));\n";
                 if (after_division[it.outputs[o]]) quotient_results.push_back("so" + std::to_string(o));
             }
 //  Windows: see the contract at the top of prelude.hpp.
             const char *low = f64 ? "0x1p-500" : (track_numerators ? "0x1p-60f" : "0x1p-100f");
             const char *high = f64 ? "0x1p+500" : (track_numerators ? "0x1p+60f" : "0x1p+100f");
-            s << "                bad = !__builtin_isfinite(finite_check) || !(dmin >= gf_magnitude(" << low
+            s << "                bad = !(vmax < __builtin_inff()) || !(dmin >= gf_magnitude(" << low
               << ")) || !(dmax <= gf_magnitude(" << high << "))";
-            for (auto &value : quotient_results) s << " || " << value << " == " << literal(0.0);
             if (track_numerators) s << " || nmin < gf_numerator_key(" << (f64 ? "0x1p-450" : "0x1p-60f") << ")";
             s << ";\n";
+//  With v_div_fixup in the quotients the sign of a zero is the IEEE one and stored zeros need no
+//  second look (GFHIP_DIV_FIXUP=1: for ensembles that keep exact zeros in their state, e.g. a
+//  symmetry plane, where this check would send every pass through the IEEE function).
+//  (the image of a double below 2^-1042 is zero as well: such a value takes the IEEE function too)
+            if (!fixup && !quotient_results.empty()) {
+                s << "                float zmin = __builtin_inff();\n";
+                for (auto &value : quotient_results) {
+                    s << "                zmin = __builtin_elementwise_minimum(zmin, gf_magnitude(" << value << "));\n";
+                }
+                s << "                zero = zmin == 0.0f;\n";
+            }
             s << "            }\n";
 //  Lanes that failed a check redo the pass with the compiler's IEEE division (the inputs of the
-//  pass are still in v*).  The status bit is set once: lanes that find it set only read it (an
-//  atomic per flagged lane on one address serialises at ~11 ns each).
-            s << "            if (__builtin_expect(bad, 0)) {\n"
-              << "                if (__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) atomicOr(flags, 1u);\n"
-              << "                {\n";
-            body(false);
-            s << "                }\n"
-              << "            }\n";
+//  pass are still in v*).  Status bit 0: a window/finite check failed; bit 1: a stored zero that
+//  came from a quotient.  A bit is set once: lanes that find it set only read it (an atomic per
+//  flagged lane on one address serialises at ~11 ns each).
+            s << "            if (__builtin_expect(bad || zero, 0)) {\n"
+              << "                const unsigned int why = bad ? 1u : 2u;\n"
+              << "                if ((__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & why) == 0u) atomicOr(flags, why);\n"
+              << "                const " << out.kernel_name << "_results redo = " << out.kernel_name << "_ieee(";
+            for (size_t i = 0; i < it.symbols.size(); i++) s << "v" << i << ", ";
+            for (size_t p = 0; p < out.packs.size(); p++) s << (out.packs[p].in_lds ? "lds" : "pack") << p << ", ";
+            if (park_slots) s << "park, park_read, ";
+            s << "0);\n";
+            for (size_t k = 0; k < it.setters.size(); k++) s << "                sv" << k << " = redo.sv" << k << ";\n";
+            for (size_t o = 0; o < it.outputs.size(); o++) s << "                so" << o << " = redo.so" << o << ";\n";
+            s << "            }\n";
         } else {
             s << "            {\n";
             body(false);
@@ -591,6 +650,8 @@ inline lowered lower(const item &original, const codegen_options &opt = codegen_
     out.has_converge = out.has_max && !it.setters.empty();
     kernel_writer writer{s, it, opt, out, parent, factor, table_pack, table_column, plan, lds_used, park_offset, park_slots,
                          use_shared, after_division};
+    if (park_slots) s << "typedef __attribute__((address_space(3))) real park_t;\n";
+    if (use_shared) writer.ieee_function();
     writer.kernel(entry::plain);
     if (out.has_max) writer.kernel(entry::max);
     if (out.has_converge) writer.kernel(entry::converge);

@@ -436,8 +436,13 @@ extern "C" int gfhip_create_kernel_call(gfhip_kernel *k, const uint64_t *input_k
     k->input_keys.assign(input_keys, input_keys + ni);
     k->output_keys.assign(output_keys, output_keys + no);
     for (size_t i = 0; i < ni; i++) {
-        if (ensure_buffer(ctx, input_keys[i], k->num_rays, k->item.dtype, input_init ? input_init[i] : nullptr,
-                          input_counts ? input_counts[i] : k->num_rays)) return 1;
+//  An input that index nodes read (index_1D/2D_node) is a buffer of its own length.
+        const size_t indexed = k->item.indexed_length(static_cast<uint32_t> (i));
+        const size_t given = input_counts ? input_counts[i] : k->num_rays;
+        size_t count = k->num_rays;
+        if (indexed > count) count = indexed;
+        if (input_init && input_init[i] && given > count) count = given;
+        if (ensure_buffer(ctx, input_keys[i], count, k->item.dtype, input_init ? input_init[i] : nullptr, given)) return 1;
     }
     for (size_t o = 0; o < no; o++) {
         if (ensure_buffer(ctx, output_keys[o], k->num_rays, k->item.dtype, nullptr)) return 1;
@@ -606,6 +611,8 @@ static int converge_on_device(gfhip_kernel *k, const double tolerance, const siz
     GFHIP_TRY(ctx, hipMemsetAsync(ctx->device_scalar, 0, sizeof(unsigned long long), ctx->stream), "hipMemsetAsync");
     GFHIP_TRY(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");     // `host` is written again below
     const unsigned int *stop = &ctx->device_converge->done;
+    const uint64_t first_launch = k->launch_count;
+    const size_t events_before = k->events.size();
     size_t batch = 16;
     for (;;) {
         for (size_t p = 0; p < batch; p++) {
@@ -618,6 +625,18 @@ static int converge_on_device(gfhip_kernel *k, const double tolerance, const siz
         GFHIP_TRY(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
         if (host.done) break;
         if (batch < 64) batch *= 2;
+    }
+//  Launch timing: keep the event pairs of the passes that ran (the first `passes` launches of the
+//  loop); the queued launches that returned at once are not launches of the item's work.
+    if (ctx->timing) {
+        size_t ran = 0;
+        for (uint64_t l = first_launch; l < first_launch + host.passes; l++) {
+            if (l % ctx->timing == 0) ran++;
+        }
+        while (k->events.size() > events_before + ran) {
+            k->free_events.push_back(k->events.back());
+            k->events.pop_back();
+        }
     }
     if (iterations_out) *iterations_out = static_cast<size_t> (host.iterations);
     if (last_max) *last_max = host.max_residual;

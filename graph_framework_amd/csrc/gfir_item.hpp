@@ -33,6 +33,19 @@ struct item {
         return dtype == GFIR_F32 ? 4 : 8;
     }
 
+///  Elements an index node reads of input `i`'s buffer (0 if none does): the buffer bound to
+///  that input must hold at least as many.
+    size_t indexed_length(const uint32_t i) const {
+        size_t length = 0;
+        for (auto &c : code) {
+            if ((c.op == GFIR_INDEX1 || c.op == GFIR_INDEX2) && c.c == i) {
+                const size_t needed = c.op == GFIR_INDEX1 ? c.aux : static_cast<size_t> (c.aux)*c.reserved;
+                if (needed > length) length = needed;
+            }
+        }
+        return length;
+    }
+
 //------------------------------------------------------------------------------
 ///  @brief Parse and validate a serialized work item.
 ///
@@ -145,6 +158,11 @@ struct item {
                     ok = before(c.a) && c.aux < h.num_tables && tables[c.aux].rows == 1; break;
                 case GFIR_GATHER2:
                     ok = before(c.a) && before(c.b) && c.aux < h.num_tables; break;
+                case GFIR_INDEX1:
+                    ok = before(c.a) && c.c < h.num_inputs && c.aux >= 1; break;
+                case GFIR_INDEX2:
+                    ok = before(c.a) && before(c.b) && c.c < h.num_inputs && c.aux >= 1 && c.reserved >= 1 &&
+                         static_cast<uint64_t> (c.aux)*c.reserved <= 0xFFFFFFFFull; break;
                 default: ok = false;
             }
             if (!ok) {

@@ -12,6 +12,7 @@
 
 #include "gfir_item.hpp"
 #include "options.hpp"
+#include "schedule.hpp"
 
 namespace gfhip {
 
@@ -44,15 +45,7 @@ inline std::vector<park_plan> plan_parking(const item &it, const codegen_options
                               : 0;
     if (opt.park_in_lds && slot_limit > 0) {
         std::vector<std::vector<size_t>> uses(node_count);
-        auto arity = [] (const uint32_t op) -> int {
-            switch (op) {
-                case GFIR_CONST: case GFIR_INPUT: return 0;
-                case GFIR_FMA: return 3;
-                case GFIR_SQRT: case GFIR_POWI: case GFIR_SIN: case GFIR_COS: case GFIR_EXP: case GFIR_LOG:
-                case GFIR_GATHER1: return 1;
-                default: return 2;
-            }
-        };
+        auto arity = [] (const uint32_t op) -> int { return operand_count(op); };
         for (size_t i = 0; i < node_count; i++) {
             const gfir_instruction &c = it.code[i];
             const uint32_t operands[3] = {c.a, c.b, c.c};

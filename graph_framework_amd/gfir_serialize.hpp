@@ -21,6 +21,7 @@
 #define gfir_serialize_h
 
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -176,11 +177,64 @@ private:
             i.imm[2] = static_cast<double> (x->get_y_scale());
             i.imm[3] = static_cast<double> (x->get_y_offset());
             slot = emit(i);
+        } else if (auto x = graph::index_1D_cast(n); x.get()) {
+//  v[idx(arg)]: the argument is compiled first, the variable is only named (piecewise.hpp:1530-1575).
+            gfir_instruction i = blank(GFIR_INDEX1);
+            i.a = lower(x->get_right());
+            i.c = input_of(x->get_left());
+            i.aux = static_cast<uint32_t> (x->get_size());
+            i.imm[0] = static_cast<double> (std::real(x->get_scale()));
+            i.imm[1] = static_cast<double> (std::real(x->get_offset()));
+            slot = emit(i);
+        } else if (auto x = graph::index_2D_cast(n); x.get()) {
+            gfir_instruction i = blank(GFIR_INDEX2);
+            i.a = lower(x->get_middle());
+            i.b = lower(x->get_right());
+            i.c = input_of(x->get_left());
+            const size_t columns = columns_of_index_2D(n.get());
+            i.aux = static_cast<uint32_t> (columns);
+            i.reserved = static_cast<uint32_t> (x->get_size()/columns);
+            i.imm[0] = static_cast<double> (std::real(x->get_x_scale()));
+            i.imm[1] = static_cast<double> (std::real(x->get_x_offset()));
+            i.imm[2] = static_cast<double> (std::real(x->get_y_scale()));
+            i.imm[3] = static_cast<double> (std::real(x->get_y_offset()));
+            slot = emit(i);
         } else {
-            throw std::runtime_error("gfir: unsupported node type (random, index, erfi or complex)");
+            throw std::runtime_error("gfir: unsupported node type (random, erfi or complex)");
         }
         slots[n.get()] = slot;
         return slot;
+    }
+
+    uint32_t input_of(graph::shared_leaf<T, SAFE_MATH> variable) {
+        auto in = inputs.find(variable.get());
+        if (in == inputs.end()) {
+            throw std::runtime_error("gfir: indexed variable is not an input of the work item");
+        }
+        return in->second;
+    }
+
+//  index_2D_node keeps its column count private (piecewise.hpp:1799, no accessor; even its
+//  is_match ignores it): the only public trace is the statement its compile() prints,
+//      const T r<node> = v<variable>[<row index>*<columns> + <column index>];
+//  (piecewise.hpp:1977-1984), which the caller hands over as `kernel_text`.
+    size_t columns_of_index_2D(graph::leaf_node<T, SAFE_MATH> *node) const {
+        if (!kernel_text) {
+            throw std::runtime_error("gfir: index_2D needs the kernel text to recover its column count");
+        }
+        const std::string start = " " + jit::to_string('r', node) + " = ";
+        const size_t statement = kernel_text->find(start);
+        const size_t end = statement == std::string::npos ? statement : kernel_text->find(';', statement);
+        if (end != std::string::npos) {
+            const std::string text = kernel_text->substr(statement, end - statement);
+            const size_t plus = text.find(" + ");
+            size_t star = plus == std::string::npos ? plus : text.rfind(")*", plus);
+            if (star != std::string::npos) {
+                const size_t columns = static_cast<size_t> (std::strtoull(text.c_str() + star + 2, nullptr, 10));
+                if (columns) return columns;
+            }
+        }
+        throw std::runtime_error("gfir: cannot find the statement of an index_2D node in the kernel text");
     }
 
     static void put(std::vector<uint8_t> &out, const void *p, const size_t bytes) {
@@ -199,6 +253,9 @@ private:
     }
 
 public:
+///  Text the nodes' compile() methods printed for this kernel (only index_2D nodes need it).
+    const std::string *kernel_text = nullptr;
+
 //------------------------------------------------------------------------------
 ///  @brief Serialize a work item.
 ///

@@ -24,6 +24,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <fstream>
 #include <functional>
 #include <iostream>
 #include <map>
@@ -32,6 +33,11 @@
 #include <vector>
 
 #include "random.hpp"
+//  The node classes the serializer walks (jit.hpp itself only needs node.hpp).
+#include "arithmetic.hpp"
+#include "math.hpp"
+#include "trigonometry.hpp"
+#include "piecewise.hpp"
 
 #include "../include/gf_hip.h"
 #include "gfir_serialize.hpp"
@@ -205,6 +211,8 @@ namespace gpu {
                     }
                 }
                 gfir::serializer<T, SAFE_MATH> serialize;
+                const std::string text = source_buffer.str();
+                serialize.kernel_text = &text;
                 item.gfir = serialize(item.name, item.inputs, kept, stores);
                 kernels[item.name] = bound_kernel{nullptr, item.inputs, kept};
             }

@@ -61,7 +61,10 @@ enum gfir_op {
     GFIR_EXP     = 13,  /* exp_node             math.hpp:337                                */
     GFIR_LOG     = 14,  /* log_node             math.hpp:602                                */
     GFIR_GATHER1 = 15,  /* piecewise_1D_node    piecewise.hpp:105  table[idx(a; imm0 scale, imm1 offset)] */
-    GFIR_GATHER2 = 16   /* piecewise_2D_node    piecewise.hpp:686  table[idx(a; imm0, imm1)*cols + idx(b; imm2, imm3)] */
+    GFIR_GATHER2 = 16,  /* piecewise_2D_node    piecewise.hpp:686  table[idx(a; imm0, imm1)*cols + idx(b; imm2, imm3)] */
+    GFIR_INDEX1  = 17,  /* index_1D_node        piecewise.hpp:1448 buffer of input c, [idx(a; imm0 scale, imm1 offset)], aux = its length */
+    GFIR_INDEX2  = 18   /* index_2D_node        piecewise.hpp:1788 buffer of input c, [idx(a; imm0, imm1)*aux + idx(b; imm2, imm3)],
+                           aux = columns, reserved = rows */
 };
 /* idx(x; scale, offset) = (uint)min(max((x - offset)/scale, 0), length - 1),
  * compile_index, piecewise.hpp:26-65. */
@@ -86,8 +89,8 @@ struct gfir_table_header {
 struct gfir_instruction {
     uint32_t op;                /* enum gfir_op */
     uint32_t a, b, c;           /* operand instruction indices (unused = 0xFFFFFFFF) */
-    uint32_t aux;               /* POWI exponent; GATHER table index */
-    uint32_t reserved;
+    uint32_t aux;               /* POWI exponent; GATHER table index; INDEX1 length; INDEX2 columns */
+    uint32_t reserved;          /* INDEX2 rows; otherwise 0 */
     double   imm[4];
 };
 

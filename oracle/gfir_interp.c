@@ -155,6 +155,14 @@ void gfi_run_##SUFFIX(const gfi_item *item, REAL **columns, REAL **outs,        
                                                                    (REAL)c->imm[3],                      \
                                                                    item->table_cols[c->aux])];           \
                     break;                                                                               \
+                case GFIR_INDEX1:                                                                            \
+                    r[i] = columns[c->c][gfi_index_##SUFFIX(r[c->a], (REAL)c->imm[0], (REAL)c->imm[1], c->aux)];    \
+                    break;                                                                                   \
+                case GFIR_INDEX2:                                                                            \
+                    r[i] = columns[c->c][gfi_index_##SUFFIX(r[c->a], (REAL)c->imm[0], (REAL)c->imm[1], c->reserved) \
+                                         *c->aux +                                                           \
+                                         gfi_index_##SUFFIX(r[c->b], (REAL)c->imm[2], (REAL)c->imm[3], c->aux)];    \
+                    break;                                                                                   \
                 default: r[i] = (REAL)NAN;                                                               \
             }                                                                                            \
         }                                                                                                \

@@ -81,7 +81,9 @@ class GpuSolver:
         self._pull()
         residual = np.empty(self.num_rays)
         self.solve.work.copy_to_host(self.residual_key, residual)
-        assert self.solve.work.context.flags() == 0
+#  bit 0: a lane left the division window (never here); bit 1 may be set: these slab scenarios keep
+#  exact zeros in their state (y, z, ky, kz), which sends the lane through the IEEE function
+        assert self.solve.work.context.flags() & 1 == 0
         return [[float(self.solve.host[k][i]) for k in STATE] + [float(residual[i])] for i in range(self.num_rays)]
 
 
