@@ -554,10 +554,12 @@ struct kernel_writer {
             s << "        out" << o << "[i] = o" << o << ";\n";
         }
         if (which == entry::max) {
-//  The max of the last output (create_max_call's argument), as the CUDA reduction's `max` takes
-//  it (cuda_context.hpp:954-995): a NaN is never selected.
+//  The max of the last output (create_max_call's argument) as cpu_context takes it — std::max_element,
+//  cpu_context.hpp:306-322: a NaN is never selected, unless it is element 0, which then stays the
+//  maximum (every `max < x` is false).  The lane that owns element 0 keeps such a NaN.
             const std::string last = "o" + std::to_string(it.outputs.size() - 1);
             s << "        lane_max = " << last << " > lane_max ? " << last << " : lane_max;\n";
+            s << "        if (i == 0ull && " << last << " != " << last << ") lane_max = " << last << ";\n";
         }
         s << "    }\n";
         if (which == entry::max) {
@@ -577,7 +579,8 @@ struct kernel_writer {
               << "        for (unsigned int w = 1; w < (blockDim.x >> 6); w++) block_max = wave_max[w] > block_max ? wave_max[w] : block_max;\n"
               << "        const " << bits << " b = __builtin_bit_cast(" << bits << ", block_max);\n"
               << "        const " << bits << " top = static_cast<" << bits << "> (1) << " << (f64 ? 63 : 31) << ";\n"
-              << "        atomicMax(reduce, static_cast<unsigned long long> ((b & top) ? static_cast<" << bits << "> (~b) : (b | top)));\n"
+              << "        atomicMax(reduce, static_cast<unsigned long long> (block_max != block_max ? static_cast<" << bits << "> (~static_cast<" << bits << "> (0))\n"
+              << "                                                             : (b & top) ? static_cast<" << bits << "> (~b) : (b | top)));\n"
               << "    }\n";
         }
         s << "}\n";

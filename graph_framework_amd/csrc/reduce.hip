@@ -46,6 +46,9 @@ max_reduce_kernel(const T *__restrict__ base, const unsigned long long total, co
     if (blockIdx.x == 0 && threadIdx.x < head) {
         m = base[threadIdx.x];
     }
+//  std::max_element (cpu_context.hpp:306-322) returns element 0 if that is a NaN: every later
+//  `max < x` is false.  Elsewhere a NaN is never selected (`v > m` is false).
+    const bool first_is_nan = total > 0 && base[0] != base[0];
 
 //  Pairs of elements per lane per load (16 B for double).
     const unsigned long long pairs = n/2;
@@ -80,6 +83,7 @@ max_reduce_kernel(const T *__restrict__ base, const unsigned long long total, co
             block = wave_max[w] > block ? wave_max[w] : block;
         }
         atomicMax(result, ordered(block));
+        if (blockIdx.x == 0 && first_is_nan) atomicMax(result, ~0ull >> (sizeof(T) == 8 ? 0 : 32));
     }
 }
 

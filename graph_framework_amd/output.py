@@ -11,9 +11,18 @@ Here the record leaves the device without stalling the step loop:
   2. the D2H copy of the snapshot into pinned host memory on a second HIP stream, ordered after
      the snapshot by an event, overlapping the following RK4 launches;
   3. a writer thread that waits for that copy and appends the record to the file.
-NetCDF-C is not in the image; the file is NetCDF-4's container format (HDF5) written through
-libhdf5 with the reference's variable names and shapes (NetCDF-4 readers open it with
-anonymous dimensions).
+NetCDF-C is not in the image; the file is written through libhdf5 in NetCDF-4's on-disk
+conventions, so that the reference's own readers (result_file(filename), output.hpp:77-78;
+reference_variable, :218-232; bin_power, graph_driver/xrays.cpp:674) find what they look up:
+  * the dimensions `time` (unlimited), `num_rays` and `ray_dim` (output.hpp:61-62, :189-197) as
+    HDF5 dimension-scale datasets the way netCDF-C writes a dimension that has no coordinate
+    variable (CLASS = "DIMENSION_SCALE", NAME = "This is a netCDF dimension but not a netCDF
+    variable.<length>", _Netcdf4Dimid; cf. `numpsi` in graph_tests/efit.nc);
+  * every variable (time, num_rays, ray_dim) with the three scales attached (DIMENSION_LIST /
+    REFERENCE_LIST through H5DSattach_scale) and _Netcdf4Coordinates;
+  * the variable `time` under netCDF-4's name for a variable that shares a dimension's name
+    without being its coordinate variable, `_nc4_non_coord_time`;
+  * the root attribute _NCProperties.
 """
 import ctypes
 import threading
@@ -21,6 +30,11 @@ import threading
 import numpy as np
 
 _CANDIDATES = ["libhdf5.so", "/opt/conda/lib/libhdf5.so.103", "/opt/conda/lib/libhdf5.so"]
+_HL_CANDIDATES = ["libhdf5_hl.so", "/opt/conda/lib/libhdf5_hl.so.100", "/opt/conda/lib/libhdf5_hl.so"]
+_H5S_SCALAR = 0
+_H5T_STR_NULLTERM = 0
+_NON_COORDINATE = "_nc4_non_coord_"
+_DIMENSION_NAME = "This is a netCDF dimension but not a netCDF variable.%10d"
 _H5F_ACC_TRUNC = 2
 _H5S_SELECT_SET = 0
 _H5S_UNLIMITED = 0xFFFFFFFFFFFFFFFF
@@ -52,15 +66,35 @@ def _hdf5():
     lib.H5Sselect_hyperslab.argtypes = [hid, ctypes.c_int] + [ctypes.c_void_p]*4
     lib.H5Dwrite.argtypes = [hid, hid, hid, hid, hid, ctypes.c_void_p]
     lib.H5Fflush.argtypes = [hid, ctypes.c_int]
-    for name in ("H5Dclose", "H5Sclose", "H5Pclose", "H5Fclose"):
+    for name in ("H5Dclose", "H5Sclose", "H5Pclose", "H5Fclose", "H5Aclose", "H5Tclose"):
         getattr(lib, name).argtypes = [hid]
+    lib.H5Screate.restype = hid
+    lib.H5Screate.argtypes = [ctypes.c_int]
+    lib.H5Tcopy.restype = hid
+    lib.H5Tcopy.argtypes = [hid]
+    lib.H5Tset_size.argtypes = [hid, ctypes.c_size_t]
+    lib.H5Tset_strpad.argtypes = [hid, ctypes.c_int]
+    lib.H5Acreate2.restype = hid
+    lib.H5Acreate2.argtypes = [hid, ctypes.c_char_p, hid, hid, hid, hid]
+    lib.H5Awrite.argtypes = [hid, hid, ctypes.c_void_p]
     lib.H5open()
+    for name in _HL_CANDIDATES:
+        try:
+            lib.hl = ctypes.CDLL(name)
+            break
+        except OSError:
+            continue
+    else:
+        raise RuntimeError("libhdf5_hl not found (tried %s)" % _HL_CANDIDATES)
+    lib.hl.H5DSset_scale.argtypes = [hid, ctypes.c_char_p]
+    lib.hl.H5DSattach_scale.argtypes = [hid, hid, ctypes.c_uint]
     return lib
 
 
 class ResultFile:
-    """output::result_file + output::data_set (output.hpp:32-400): variables of shape
-    (time, num_rays, 1) with an unlimited time dimension, one record appended per write."""
+    """output::result_file + output::data_set (output.hpp:32-400): the dimensions time
+    (unlimited), num_rays, ray_dim; variables of shape (time, num_rays, ray_dim); one record
+    appended per write."""
 
     def __init__(self, path, num_rays, dtype=np.float64):
         self.lib = _hdf5()
@@ -69,29 +103,92 @@ class ResultFile:
         hid = ctypes.c_int64
         native = "H5T_NATIVE_DOUBLE_g" if self.dtype == np.float64 else "H5T_NATIVE_FLOAT_g"
         self.native = hid.in_dll(self.lib, native).value
+        self.native_int = hid.in_dll(self.lib, "H5T_NATIVE_INT_g").value
+        self.string = hid.in_dll(self.lib, "H5T_C_S1_g").value
+        self.scale_type = hid.in_dll(self.lib, "H5T_IEEE_F32BE_g").value
         self.dataset_create = hid.in_dll(self.lib, "H5P_CLS_DATASET_CREATE_ID_g").value
         self.file = self.lib.H5Fcreate(path.encode(), _H5F_ACC_TRUNC, 0, 0)
         if self.file < 0:
             raise IOError("cannot create %s" % path)
         self.variables = {}
         self.records = 0
+        self._string_attribute(self.file, "_NCProperties", "version=2,graph_framework_amd=1,hdf5=1.10", None)
+#  result_file's constructor (output.hpp:61-64) and data_set's (output.hpp:189-197).
+        self.dimensions = [self._dimension("time", None, 0), self._dimension("num_rays", max(self.num_rays, 1), 1),
+                           self._dimension("ray_dim", 1, 2)]
+
+    def _string_attribute(self, where, name, text, size):
+        data = text.encode()
+        size = size or len(data) + 1
+        kind = self.lib.H5Tcopy(self.string)
+        self.lib.H5Tset_size(kind, size)
+        self.lib.H5Tset_strpad(kind, _H5T_STR_NULLTERM)
+        space = self.lib.H5Screate(_H5S_SCALAR)
+        attribute = self.lib.H5Acreate2(where, name.encode(), kind, space, 0, 0)
+        if attribute < 0:
+            raise IOError("cannot create attribute %s" % name)
+        buffer = ctypes.create_string_buffer(data, size)
+        self.lib.H5Awrite(attribute, kind, buffer)
+        self.lib.H5Aclose(attribute)
+        self.lib.H5Sclose(space)
+        self.lib.H5Tclose(kind)
+
+    def _int_attribute(self, where, name, values):
+        values = list(values)
+        if len(values) == 1:
+            space = self.lib.H5Screate(_H5S_SCALAR)
+        else:
+            space = self.lib.H5Screate_simple(1, (ctypes.c_uint64*1)(len(values)), None)
+        attribute = self.lib.H5Acreate2(where, name.encode(), self.native_int, space, 0, 0)
+        if attribute < 0:
+            raise IOError("cannot create attribute %s" % name)
+        self.lib.H5Awrite(attribute, self.native_int, (ctypes.c_int*len(values))(*values))
+        self.lib.H5Aclose(attribute)
+        self.lib.H5Sclose(space)
+
+    def _dimension(self, name, length, dimid):
+        """A netCDF-4 dimension without a coordinate variable: a dimension-scale dataset of the
+        dimension's length (unlimited: extensible, extended with the records)."""
+        plist = self.lib.H5Pcreate(self.dataset_create)
+        if length is None:
+            space = self.lib.H5Screate_simple(1, (ctypes.c_uint64*1)(0), (ctypes.c_uint64*1)(_H5S_UNLIMITED))
+            self.lib.H5Pset_chunk(plist, 1, (ctypes.c_uint64*1)(1024))
+        else:
+            space = self.lib.H5Screate_simple(1, (ctypes.c_uint64*1)(length), None)
+        dataset = self.lib.H5Dcreate2(self.file, name.encode(), self.scale_type, space, 0, plist, 0)
+        self.lib.H5Pclose(plist)
+        self.lib.H5Sclose(space)
+        if dataset < 0:
+            raise IOError("cannot create dimension %s" % name)
+        if self.lib.hl.H5DSset_scale(dataset, None) < 0:            # CLASS = "DIMENSION_SCALE"
+            raise IOError("H5DSset_scale failed for %s" % name)
+        self._string_attribute(dataset, "NAME", _DIMENSION_NAME % (0 if length is None else length), 64)
+        self._int_attribute(dataset, "_Netcdf4Dimid", [dimid])
+        return dataset
 
     def create_variable(self, name):
+        """data_set::create_variable (output.hpp:260-273): nc_def_var(name, type, {time, num_rays, ray_dim})."""
         dims = (ctypes.c_uint64*3)(0, self.num_rays, 1)
         maxdims = (ctypes.c_uint64*3)(_H5S_UNLIMITED, self.num_rays, 1)
         chunk = (ctypes.c_uint64*3)(1, max(self.num_rays, 1), 1)
         space = self.lib.H5Screate_simple(3, dims, maxdims)
         plist = self.lib.H5Pcreate(self.dataset_create)
         self.lib.H5Pset_chunk(plist, 3, chunk)
-        dataset = self.lib.H5Dcreate2(self.file, name.encode(), self.native, space, 0, plist, 0)
+#  A variable that shares a dimension's name without being its coordinate variable.
+        stored = _NON_COORDINATE + name if name in ("time", "num_rays", "ray_dim") else name
+        dataset = self.lib.H5Dcreate2(self.file, stored.encode(), self.native, space, 0, plist, 0)
         self.lib.H5Pclose(plist)
         self.lib.H5Sclose(space)
         if dataset < 0:
             raise IOError("cannot create variable %s" % name)
+        for index, scale in enumerate(self.dimensions):
+            if self.lib.hl.H5DSattach_scale(dataset, scale, index) < 0:
+                raise IOError("H5DSattach_scale failed for %s" % name)
+        self._int_attribute(dataset, "_Netcdf4Coordinates", [0, 1, 2])
         self.variables[name] = dataset
 
     def write(self, record):
-        """Append one record: {variable: array of num_rays}."""
+        """Append one record: {variable: array of num_rays} (data_set::write, output.hpp:354-400)."""
         extent = (ctypes.c_uint64*3)(self.records + 1, self.num_rays, 1)
         start = (ctypes.c_uint64*3)(self.records, 0, 0)
         count = (ctypes.c_uint64*3)(1, self.num_rays, 1)
@@ -109,10 +206,11 @@ class ResultFile:
             if status < 0:
                 raise IOError("H5Dwrite failed for %s" % name)
         self.records += 1
+        self.lib.H5Dset_extent(self.dimensions[0], (ctypes.c_uint64*1)(self.records))    # the length of `time`
 
     def close(self):
         if self.file is not None:
-            for dataset in self.variables.values():
+            for dataset in list(self.variables.values()) + self.dimensions:
                 self.lib.H5Dclose(dataset)
             self.lib.H5Fclose(self.file)
             self.file = None

@@ -165,3 +165,46 @@ class RaySolver:
 class Rk4ColdPlasmaEfit(RaySolver):
     """solver::rk4<dispersion::cold_plasma<T>> on an EFIT equilibrium (the xrays_bench
     combination; `dispersion="ordinary_wave"` selects physics_test.cpp:583-618's)."""
+
+
+class AdaptiveRk4ColdPlasmaEfit(RaySolver):
+    """solver::adaptive_rk4<dispersion::cold_plasma<T>> on the EFIT equilibrium (solver.hpp:877-1006,
+    `--solver=adaptive_rk4` of graph_driver/xrays.cpp:353): dt is a per-ray variable, and every
+    step first runs a converge item on the two unknowns (dt, lambda) of 1/dt + lambda*D(next)^2
+    (newton.hpp:34-51), then the RK4 step with that dt — the two items of adaptive_rk4::compile
+    (solver.hpp:951-1003) in the order workflow::manager::run executes them.
+
+    On the reference's own graph layer that converge item drives dt and lambda to NaN inside the
+    first step (tests/golden/make_adaptive_golden.py records it); this class reproduces the
+    reference, it does not repair it."""
+
+    def __init__(self, state, dt=1.0e-3, **kwargs):
+        super().__init__(state, **kwargs)
+        self.host["dt"] = np.full(self.num_rays, dt, dtype=self.np_dtype)
+        self.host["lambda"] = np.full(self.num_rays, 1.0, dtype=self.np_dtype)       # solver.hpp:953
+        self.adaptive = None
+        self.adaptive_iterations = []
+
+    def compile(self, tolerance=1.0e-30, max_iterations=1000):
+        work = self.work
+        initial = dict(self._initial(), **{self.prefix + "dt": self.host["dt"], self.prefix + "lambda": self.host["lambda"]})
+        keys = self.keys + [self.prefix + "dt", self.prefix + "lambda"]
+        self.adaptive = work.add_converge_item(self._item("adaptive_rk4_loss_kernel"), keys, [self.prefix + "adaptive_loss"],
+                                               self.num_rays, initial, tolerance, max_iterations)
+        self.solver = work.add_item(self._item("adaptive_rk4_solver_kernel"), keys[:-1], [self.residual_key],
+                                    self.num_rays, initial)
+        work.context.compile()
+        self.adaptive.create_kernel_call()
+        self.solver.create_kernel_call()
+
+    def step(self, steps=1):
+        for _ in range(steps):
+            self.adaptive.run()
+            self.adaptive_iterations.append(self.adaptive.iterations)
+            self.solver.run(1)
+
+    def sync_host(self):
+        super().sync_host()
+        for k in ("dt", "lambda"):
+            self.work.copy_to_host(self.prefix + k, self.host[k])
+        return self.host

@@ -680,5 +680,43 @@ work_item<T> make_solver_kernel(const ray_variables<T> &v, equilibrium_base<T> &
                           {s.x_next, v.x}, {s.y_next, v.y}, {s.z_next, v.z}, {s.t_next, v.t}});
 }
 
+// ---------------------------------------------------------------------------
+// solver::adaptive_rk4, solver.hpp:877-1006: the RK4 step with dt a VARIABLE, and before every
+// step a Newton converge item (newton.hpp:34-51) on the two unknowns (dt, lambda) of
+//     loss = 1/dt + lambda*D(next state)^2,
+// where the next state enters a second dispersion_interface through pseudo variables
+// (solver.hpp:937-947), so that d(loss)/d(dt) sees only the 1/dt term.
+// compile() (solver.hpp:951-1003): item 1 = the converge item `loss_kernel` over
+// {t,w,x,y,z,kx,ky,kz,dt,lambda}; item 2 = `solver_kernel` over {t,...,kz,dt}.
+// ---------------------------------------------------------------------------
+template<typename T>
+struct adaptive_rk4_items {
+    leaf<T> dt, lambda;
+    std::unique_ptr<work_item<T>> loss, solver;
+};
+
+template<typename T>
+adaptive_rk4_items<T> make_adaptive_rk4(const ray_variables<T> &v, equilibrium_base<T> &eq, dispersion_interface<T> &D) {
+    adaptive_rk4_items<T> items;
+    items.dt = graph::variable<T> (1, "dt");
+    items.lambda = graph::variable<T> (1, "\\lambda");
+    const rk4_step<T> s = make_rk4_step<T> (v, eq, items.dt, D);
+    dispersion_interface<T> next(v.w, graph::pseudo_variable(s.kx_next), graph::pseudo_variable(s.ky_next),
+                                 graph::pseudo_variable(s.kz_next), graph::pseudo_variable(s.x_next),
+                                 graph::pseudo_variable(s.y_next), graph::pseudo_variable(s.z_next), eq, D.function);
+    auto loss = graph::one<T> ()/items.dt + items.lambda*next.D*next.D;
+    std::vector<leaf<T>> inputs = v.inputs();
+    inputs.push_back(items.dt);
+    inputs.push_back(items.lambda);
+    const T step = static_cast<T> (1.0);
+    items.loss.reset(new work_item<T> (inputs, {loss*loss},
+                                       {{items.dt - step*loss/loss->df(items.dt), items.dt},
+                                        {items.lambda - step*loss/loss->df(items.lambda), items.lambda}}));
+    inputs.pop_back();
+    items.solver.reset(new work_item<T> (inputs, {s.residual},
+                                         {{s.kx_next, v.kx}, {s.ky_next, v.ky}, {s.kz_next, v.kz},
+                                          {s.x_next, v.x}, {s.y_next, v.y}, {s.z_next, v.z}, {s.t_next, v.t}}));
+    return items;
+}
 
 #endif /* ref_builders_hpp */

@@ -155,6 +155,67 @@ static int cmd_trace(const raw_tables &raw, const char *in_path, const char *out
     return 0;
 }
 
+//  solver::adaptive_rk4 on the EFIT cold-plasma ray (graph_driver/xrays.cpp:353 `--solver=adaptive_rk4`):
+//  Newton init of kx, then per step the converge item on (dt, lambda) and the RK4 step with that dt,
+//  as workflow::manager::run executes the two items (workflow.hpp:359-363).  Columns: the 8 state
+//  arrays, dt, lambda; records: those 10 + residual + the converge item's iteration count.
+//  With `export_dir` the two items are also written as GFIR.
+template<typename T>
+static int cmd_trace_adaptive(const raw_tables &raw, const char *in_path, const char *out_path,
+                              const size_t num_steps, const char *export_dir, const char *suffix) {
+    efit<T> eq(raw);
+    size_t n;
+    auto cols = convert<T> (read_columns(in_path, 10, n));
+    ray_variables<T> v;
+    dispersion_interface<T> D(v.w, v.kx, v.ky, v.kz, v.x, v.y, v.z, eq, cold_plasma_D<T>);
+    std::vector<T> residual(n, 0), loss_value(n, 0);
+    work_item<T> newton_kx = make_loss_kernel(v, D.D, 1, static_cast<T> (1.0));
+    T last;
+    const size_t it = converge(newton_kx, n, pointers(cols, 0, 8), residual.data(), static_cast<T> (1.0E-30), 1000, &last);
+    fprintf(stderr, "{\"newton_iterations\": %zu}\n", it);
+
+    adaptive_rk4_items<T> items = make_adaptive_rk4<T> (v, eq, D);
+    fprintf(stderr, "adaptive loss_kernel ");
+    items.loss->code.print_counts(stderr);
+    fprintf(stderr, "adaptive solver_kernel ");
+    items.solver->code.print_counts(stderr);
+    if (export_dir && export_dir[0]) {
+        items.loss->write_gfir("adaptive_loss_kernel", std::string(export_dir) + "/adaptive_rk4_loss_kernel_" + suffix + ".gfir");
+        items.solver->write_gfir("adaptive_solver_kernel", std::string(export_dir) + "/adaptive_rk4_solver_kernel_" + suffix + ".gfir");
+    }
+
+//  The first converge loop pass by pass, on a copy of the state: (dt, lambda, loss^2) after each
+//  pass — what the device has to reproduce before everything turns NaN (<out>.passes).
+    {
+        auto copy = cols;
+        std::vector<std::vector<double>> passes;
+        for (int pass = 0; pass < 24; pass++) {
+            items.loss->run(n, pointers(copy, 0, 10), {loss_value.data()});
+            passes.emplace_back(copy[8].begin(), copy[8].end());
+            passes.emplace_back(copy[9].begin(), copy[9].end());
+            passes.emplace_back(loss_value.begin(), loss_value.end());
+        }
+        write_columns((std::string(out_path) + ".passes").c_str(), passes);
+    }
+
+    std::vector<std::vector<double>> record;
+    std::vector<double> iterations(n, 0.0);
+    auto save = [&] () {
+        for (size_t c = 0; c < 10; c++) record.emplace_back(cols[c].begin(), cols[c].end());
+        record.emplace_back(residual.begin(), residual.end());
+        record.emplace_back(iterations);
+    };
+    save();
+    for (size_t s = 1; s <= num_steps; s++) {
+        const size_t used = converge(*items.loss, n, pointers(cols, 0, 10), loss_value.data(), static_cast<T> (1.0E-30), 1000, &last);
+        std::fill(iterations.begin(), iterations.end(), static_cast<double> (used));
+        items.solver->run(n, pointers(cols, 0, 9), {residual.data()});
+        save();
+    }
+    write_columns(out_path, record);
+    return 0;
+}
+
 //  graph_korc/xkorc.cpp:29-121 + efit::get_characteristic_field equilibrium.hpp:1585-1615.
 template<typename T>
 struct korc_graphs {
@@ -591,6 +652,8 @@ static int dispatch(const raw_tables &raw, int argc, char **argv) {
     } else if (cmd == "trace" && argc == 10) {
         return cmd_trace<T> (raw, argv[4], argv[5], atof(argv[6]), strtoull(argv[7], nullptr, 10),
                              strtoull(argv[8], nullptr, 10), atoi(argv[9]));
+    } else if (cmd == "trace_adaptive" && argc == 9) {
+        return cmd_trace_adaptive<T> (raw, argv[4], argv[5], strtoull(argv[6], nullptr, 10), argv[7], argv[8]);
     } else if (cmd == "export_misc" && argc == 6) {
         return cmd_export_misc<T> (argv[4], argv[5]);
     } else if (cmd == "export_korc" && argc == 6) {

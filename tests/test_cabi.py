@@ -56,9 +56,9 @@ def test_lowering_without_a_device(lib):
     assert len(re.findall(r"= gf_rcp\(", source)) == 82
     assert len(re.findall(r"const real r\d+ = gf_div\(r", source)) == 680
     assert len(re.findall(r"const real x\d+ = gf_div\(r", source)) == 12
-    # the second body: the same pass with the compiler's IEEE division, for lanes that fail a check
+    # the IEEE function: the same pass with the compiler's division, for lanes that fail a check
     assert len(re.findall(r"const real r\d+ = r\d+(?:p\d+)?/r\d+(?:p\d+)?;", source)) == 680
-    assert source.count("if (__builtin_expect(bad, 0))") == 1
+    assert source.count("gfhip_solver_kernel_ieee(") == 2 and source.count("if (__builtin_expect(bad || zero, 0))") == 1
     again, again_hash = generate_source(os.path.join(WORKLOADS, "solver_kernel_f64.gfir"))
     assert again == source and again_hash == source_hash
 
@@ -144,7 +144,8 @@ def test_result_file_roundtrip(tmp_path):
     out.close()
     f = H5File(path)
     x = f.read("x")
-    time = f.read("time")
+    time = f.read("_nc4_non_coord_time")          # netCDF-4's name for a variable called like a dimension
+    assert f.read("time").shape == (3,)           # the dimension `time` itself: its length is the record count
     f.close()
     assert x.shape == (3, 5, 1) and time.shape == (3, 5, 1)
     np.testing.assert_array_equal(x[2, :, 0], np.arange(5.0) + 2)
@@ -174,7 +175,7 @@ def _defined_before_use(source, kernel):
     body = source[source.index(kernel + "("):]
 #  the first body of the first entry point (the IEEE second body and the other entry points
 #  repeat the same pass)
-    for marker in ("if (__builtin_expect(bad, 0))", 'extern "C" __global__'):
+    for marker in ("if (__builtin_expect(bad || zero, 0))", 'extern "C" __global__'):
         if marker in body:
             body = body[:body.index(marker)]
     defined = set()
@@ -232,3 +233,52 @@ def test_lowering_under_address_and_ub_sanitizers(tmp_path):
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.startswith("lowered")
+
+
+def test_result_file_has_the_reference_netcdf4_dimensions(tmp_path):
+    """graph_framework_amd/output.py writes result<n>.nc in NetCDF-4's on-disk conventions, so that
+    the reference's readers find what they look up: nc_inq_dimid "time" / "num_rays"
+    (output.hpp:77-78), "ray_dim" (:189-193), variables of dimensions (time, num_rays, ray_dim)
+    (:260-273, :218-232).  No NetCDF library exists in the image; the header is checked against
+    the structure netCDF-C itself wrote into the reference's fixtures (cf. `h5dump -H -A` of
+    graph_tests/efit.nc: CLASS, NAME, _Netcdf4Dimid, DIMENSION_LIST, REFERENCE_LIST)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_fixtures import H5File
+    from graph_framework_amd.output import ResultFile, RAY_VARIABLES
+    h5dump = "/opt/conda/bin/h5dump"
+    if not os.path.exists(h5dump):
+        pytest.skip("h5dump not available")
+    path = str(tmp_path / "result0.nc")
+    n = 7
+    result = ResultFile(path, n)
+    for name, _ in RAY_VARIABLES:
+        result.create_variable(name)
+    records = [{name: np.arange(n) + 10.0*r + i for i, (name, _) in enumerate(RAY_VARIABLES)} for r in range(4)]
+    for record in records:
+        result.write(record)
+    result.close()
+
+    header = subprocess.run([h5dump, "-H", "-A", path], capture_output=True, text=True, check=True).stdout
+    flat = " ".join(header.split())
+    assert 'DATASET "time" { DATATYPE H5T_IEEE_F32BE DATASPACE SIMPLE { ( 4 ) / ( H5S_UNLIMITED ) }' in flat
+    assert 'DATASET "num_rays" { DATATYPE H5T_IEEE_F32BE DATASPACE SIMPLE { ( 7 ) / ( 7 ) }' in flat
+    assert 'DATASET "ray_dim" { DATATYPE H5T_IEEE_F32BE DATASPACE SIMPLE { ( 1 ) / ( 1 ) }' in flat
+    assert flat.count('"DIMENSION_SCALE"') == 3
+    for length in (0, 7, 1):
+        assert ('"This is a netCDF dimension but not a netCDF variable.%10d"' % length) in header
+    assert flat.count('ATTRIBUTE "_Netcdf4Dimid"') == 3 and '"_NCProperties"' in flat
+    for name, _ in RAY_VARIABLES:
+        stored = "_nc4_non_coord_time" if name == "time" else name
+        assert ('DATASET "%s" { DATATYPE H5T_IEEE_F64LE DATASPACE SIMPLE { ( 4, 7, 1 ) / ( H5S_UNLIMITED, 7, 1 ) }' % stored) in flat
+    assert flat.count("(DATASET") == 3*len(RAY_VARIABLES)               # every variable lists its three scales
+    assert flat.count('/time ), (DATASET') == len(RAY_VARIABLES)
+
+    f = H5File(path)
+    for i, (name, _) in enumerate(RAY_VARIABLES):
+        data = f.read("_nc4_non_coord_time" if name == "time" else name)
+        for r in range(4):
+            np.testing.assert_array_equal(data[r, :, 0], records[r][name])
+    f.close()

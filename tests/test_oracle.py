@@ -241,3 +241,33 @@ def test_reference_test_scenarios_match_reference_bit_for_bit(physics_golden, na
     result = scenario(OracleSolver)
     physics_scenarios.compare(result, physics_golden[name], exact=True)
     assert result["holds"]
+
+
+def test_adaptive_rk4_on_the_oracle_matches_the_reference_graph_layer():
+    """solver::adaptive_rk4 (solver.hpp:877-1006): the CPU oracle on the two exported items
+    against the records of the reference's own graph layer (tests/golden/adaptive_rk4_golden.npz,
+    written by make_adaptive_golden.py through oracle/_ref/gf_ref): every pass of the first
+    converge loop on (dt, lambda), its iteration count (22), and the state after it — which is
+    NaN: on the reference graph this integrator loses every ray in its first step."""
+    from oracle import gfir
+    golden = np.load(os.path.join(GOLDEN, "adaptive_rk4_golden.npz"))
+    columns = [c.copy() for c in golden["inputs"]]
+    iterations, _, _ = gfir.Item(os.path.join(WORKLOADS, "loss_kernel_kx_f64.gfir")).converge(columns[:8])
+    assert iterations == int(golden["newton_iterations"])
+    loss = gfir.Item(os.path.join(WORKLOADS, "adaptive_rk4_loss_kernel_f64.gfir"))
+    solver = gfir.Item(os.path.join(WORKLOADS, "adaptive_rk4_solver_kernel_f64.gfir"))
+    trial = [c.copy() for c in columns]
+    with np.errstate(all="ignore"):
+        for p in range(24):
+            outs, _ = loss.run(trial)
+            for got, want in zip((trial[8], trial[9], outs[0]), golden["passes"][p]):
+                assert np.array_equal(got, want, equal_nan=True), p
+        for step in range(1, golden["records"].shape[0]):
+            used, _, _ = loss.converge(columns)
+            outs, _ = solver.run(columns[:9])
+            record = golden["records"][step]
+            assert used == int(record[11, 0])
+            for c in range(10):
+                assert np.array_equal(columns[c], record[c], equal_nan=True), (step, c)
+            assert np.array_equal(outs[0], record[10], equal_nan=True)
+    assert int(golden["records"][1, 11, 0]) == 22 and np.isnan(golden["records"][1, 2]).all()
