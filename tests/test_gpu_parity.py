@@ -129,13 +129,14 @@ def test_solver_kernel_random_rays_vs_oracle():
 
 
 def test_full_size_ensembles_through_size_independent_properties(golden_ref):
-    """BASELINE.json's sizes (1e6 identical rays; 1e6 incoherent rays), where the oracle cannot
-    follow: the properties every ray-independent kernel must keep.
+    """BASELINE.json's sizes (configs[1]: 1e6 identical rays; configs[2]: 1e7 incoherent rays),
+    where the oracle cannot follow: the properties every ray-independent kernel must keep.
       * 1e6 identical rays, 100 steps: every lane holds the bits of lane 0, and lane 0 holds the
         reference's record of step 100 (tests/golden/ref_golden.npz);
       * incoherent rays: a ray's trajectory depends on nothing but its own state — the ensemble
         run in one piece, in reversed order and as two unequal shards gives every ray the same
-        bits (tile, lane, workgroup and grid position do not matter)."""
+        bits (tile, lane, workgroup and grid position do not matter) — and 64 rays picked across
+        the 1e7 equal the oracle's trace of each of them alone, bit for bit."""
     from graph_framework_amd.xrays import Rk4ColdPlasmaEfit, cli_distribution
     n = 1000000
     solve = Rk4ColdPlasmaEfit(bench_state(n))
@@ -164,10 +165,10 @@ def test_full_size_ensembles_through_size_independent_properties(golden_ref):
         assert run.work.context.flags() == 0
         return out
 
-    rays = cli_distribution(n, seed=3)
+    rays = cli_distribution(10000000, seed=3)
     whole = trace(rays)
     backwards = trace({k: np.ascontiguousarray(v[::-1]) for k, v in rays.items()})
-    cut = 333337
+    cut = 3333337
     first = trace({k: np.ascontiguousarray(v[:cut]) for k, v in rays.items()})
     second = trace({k: np.ascontiguousarray(v[cut:]) for k, v in rays.items()})
     for k in list(STATE) + ["residual"]:
@@ -175,6 +176,18 @@ def test_full_size_ensembles_through_size_independent_properties(golden_ref):
         assert np.array_equal(whole[k][:cut], first[k], equal_nan=True), k
         assert np.array_equal(whole[k][cut:], second[k], equal_nan=True), k
     assert np.isfinite(whole["x"]).all() and np.ptp(whole["kz"]) > 1.0      # a genuinely incoherent beam
+    picked = np.linspace(0, rays["x"].size - 1, 64).astype(np.int64)
+    columns = [np.ascontiguousarray(rays[k][picked]) for k in STATE]
+    loss, item = _oracle("loss_kernel_kx_f64.gfir"), _oracle("solver_kernel_f64.gfir")
+    for i in range(picked.size):                          # the converge loop on each ray alone
+        single = [c[i:i + 1].copy() for c in columns]
+        loss.converge(single)
+        for c, value in zip(columns, single):
+            c[i] = value[0]
+    outs, _ = item.run(columns, steps=20)
+    for k, expected in zip(STATE, columns):
+        assert np.array_equal(whole[k][picked], expected), k
+    assert np.array_equal(whole["residual"][picked], outs[0])
 
 
 def test_incoherent_beam_500_steps_including_rays_that_blow_up():
