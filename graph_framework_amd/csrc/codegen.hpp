@@ -95,8 +95,6 @@ struct kernel_writer {
     const uint32_t park_slots;
     const bool use_shared;                          ///< shared-reciprocal division with the IEEE second body
     const std::vector<bool> &after_division;        ///< node depends on the result of a division
-    const bool prefetch;                            ///< next-tile prefetch (see tile_open)
-    const size_t prefetch_position;                 ///< ... emitted before this record of the pass
 
     const bool f64 = it.dtype == GFIR_F64;
     const bool track_numerators = opt.division == division_mode::checked;
@@ -123,7 +121,7 @@ struct kernel_writer {
 //  The node-for-node body.  `shared` = divisions through a reciprocal shared by all
 //  divisions with the same denominator (gf_rcp/gf_div in the prelude) plus the checks that
 //  tell whether the lane may keep that result; otherwise the compiler's IEEE division.
-    void body(const bool shared, const bool with_prefetch = false) {
+    void body(const bool shared) {
         typedef std::tuple<uint32_t, uint32_t, uint32_t, uint32_t, double, double, double, double> group_key;
         std::map<group_key, std::string> groups;
         std::map<uint32_t, bool> reciprocal_done;
@@ -195,28 +193,7 @@ struct kernel_writer {
             s << ind << "const real r" << v << " = " << value << ";\n";
             deferred.erase(found);
         };
-        std::string last_group;                                            // index group of the latest gather
-        for (size_t i = 0; i <= it.code.size(); i++) {
-            if (with_prefetch && i == prefetch_position) {
-//  Next-tile prefetch.  A small item's pass is a dependency chain — state loads (HBM latency),
-//  index, coefficient gathers (L2), arithmetic, stores — and few waves fit a SIMD (3 for the
-//  EFIT Newton kernel), so the chain's latency, not a roofline, sets the rate.  The next tile's
-//  state is therefore requested from inside this pass.  vmcnt retires in order: a load issued
-//  BEFORE the coefficient gathers would make their wait last as long as the HBM access, so the
-//  prefetch goes right after the last global gather has been ISSUED (its address is tied to that
-//  gather's index, not to its result).  Unconditional (a branch would split the scheduling
-//  region): passes before the last one of a fused launch, and the last tile, re-read this
-//  tile's own element.
-                s << ind << "unsigned long long ahead = (step + 1u == steps && i + stride < n) ? i + stride : i;\n";
-                if (!last_group.empty()) {
-                    s << ind << "asm volatile(\"\" : \"+v\"(ahead) : \"v\"(" << last_group << "));\n";
-                }
-                for (size_t k = 0; k < it.symbols.size(); k++) {
-                    s << ind << "next" << k << " = in" << k << "[ahead];\n";
-                }
-                s << ind << "__builtin_amdgcn_sched_barrier(0);\n";
-            }
-            if (i == it.code.size()) break;
+        for (size_t i = 0; i < it.code.size(); i++) {
             const gfir_instruction &c = it.code[i];
             reload(i);
             {
@@ -307,7 +284,6 @@ struct kernel_writer {
                         s << ")*" << p.stride << "u;\n";
                         g = groups.insert({key, group_name}).first;
                     }
-                    last_group = g->second;
 //  A derived table's value (k*parent) is defined at its first use, not here: next to the
 //  parent's load it would make the pass wait for that load at once.  The load stays here.
                     if (parent[c.aux] >= 0 && !plan[i].parked) {
@@ -448,24 +424,14 @@ struct kernel_writer {
         if (which == entry::max) {
             s << "    real lane_max = -__builtin_huge_val" << sfx << "();\n";
         }
-        const bool ahead = prefetch && which != entry::converge;
-        if (ahead) {
-            s << "    const unsigned long long stride = gridDim.x*static_cast<unsigned long long> (blockDim.x);\n"
-              << "    unsigned long long i = blockIdx.x*static_cast<unsigned long long> (blockDim.x) + threadIdx.x;\n";
-            for (size_t k = 0; k < it.symbols.size(); k++) {
-                s << "    real next" << k << " = i < n ? in" << k << "[i] : " << literal(0.0) << ";\n";
-            }
-            s << "    for (; i < n; i += stride) {\n";
-        } else {
-            s << "    for (unsigned long long i = blockIdx.x*static_cast<unsigned long long> (blockDim.x) + threadIdx.x; i < n;\n"
-              << "         i += gridDim.x*static_cast<unsigned long long> (blockDim.x)) {\n";
-        }
+        s << "    for (unsigned long long i = blockIdx.x*static_cast<unsigned long long> (blockDim.x) + threadIdx.x; i < n;\n"
+          << "         i += gridDim.x*static_cast<unsigned long long> (blockDim.x)) {\n";
         for (size_t i = 0; i < it.symbols.size(); i++) {
             std::string symbol = it.symbols[i];
             for (auto &ch : symbol) {
                 if (ch == '\\' || ch == '\n' || ch == '\r') ch = ' ';
             }
-            s << "        real v" << i << " = " << (ahead ? "next" + std::to_string(i) : "in" + std::to_string(i) + "[i]") << ";  // " << symbol << "\n";
+            s << "        real v" << i << " = in" << i << "[i];  // " << symbol << "\n";
         }
         for (size_t o = 0; o < it.outputs.size(); o++) {
             s << "        real o" << o << " = " << literal(0.0) << ";\n";
@@ -501,7 +467,7 @@ struct kernel_writer {
             s << "                float dmax = gf_magnitude(" << literal(1.0) << "), dmin = dmax;   // extreme |denominator| of this pass\n";
             s << "                float vmax = dmax;                                   // extreme |stored value|, |index quotient|\n";
             if (track_numerators) s << "                unsigned int nmin = 0xFFFFFFFFu;                    // smallest non-zero |numerator| key\n";
-            body(true, prefetch && which != entry::converge);
+            body(true);
 //  The finite checks run on the same fp32 image as the window check (a non-finite value, or a
 //  double of 2^1017 and more, reads as a float NaN/infinity and fails the comparison): half a
 //  v_maximum3_f32 per value.
@@ -550,7 +516,7 @@ struct kernel_writer {
             s << "            }\n";
         } else {
             s << "            {\n";
-            body(false, prefetch && which != entry::converge);
+            body(false);
             s << "            }\n";
         }
         for (size_t o = 0; o < it.outputs.size(); o++) {
@@ -685,32 +651,8 @@ inline lowered lower(const item &original, const codegen_options &opt = codegen_
     const bool small = it.code.size() <= 1500;
     out.has_max = !it.outputs.empty() && small;
     out.has_converge = out.has_max && !it.setters.empty();
-//  Next-tile prefetch for small items (kernel_writer::body): after the last gather that goes
-//  through global memory (a 2-D table pack outside LDS, an index node), or at the top of the pass.
-    const bool prefetch = (opt.prefetch_next_tile < 0 ? small : opt.prefetch_next_tile == 1) && !it.symbols.empty();
-    size_t prefetch_position = 0;
-    {
-//  A stored table is loaded where the first gather of its index group needs it or one of its
-//  multiples (kernel_writer::body, value_at); later gathers of the group reuse the value.
-        typedef std::tuple<uint32_t, uint32_t, double, double, double, double, uint32_t> load_key;
-        std::set<load_key> loaded;
-        for (size_t i = 0; i < it.code.size(); i++) {
-            const gfir_instruction &c = it.code[i];
-            if (c.op == GFIR_INDEX1 || c.op == GFIR_INDEX2) {
-                prefetch_position = i + 1;
-            } else if ((c.op == GFIR_GATHER1 || c.op == GFIR_GATHER2) && !out.packs[table_pack[c.aux]].in_lds) {
-                uint32_t root = c.aux;
-                while (parent[root] >= 0) root = static_cast<uint32_t> (parent[root]);
-                const bool two = c.op == GFIR_GATHER2;
-                if (loaded.insert(load_key(c.a, two ? c.b : GFIR_NONE, c.imm[0], c.imm[1], two ? c.imm[2] : 0.0,
-                                           two ? c.imm[3] : 0.0, root)).second) {
-                    prefetch_position = i + 1;
-                }
-            }
-        }
-    }
     kernel_writer writer{s, it, opt, out, parent, factor, table_pack, table_column, plan, lds_used, park_offset, park_slots,
-                         use_shared, after_division, prefetch, prefetch_position};
+                         use_shared, after_division};
     if (park_slots) s << "typedef __attribute__((address_space(3))) real park_t;\n";
     if (use_shared) writer.ieee_function();
     writer.kernel(entry::plain);

@@ -4,8 +4,8 @@
 ///  generated text and therefore the kernel-cache key), the cache hash and the compile flags.
 ///
 ///  Alternatives that were measured neutral or slower on MI355X (packed fp32 pairs, 2/4 rays per
-///  lane, pipelined tiles, scheduling fences, explicit order files) are recorded in DESIGN.md and
-///  are no longer part of the lowering.
+///  lane, next-tile prefetch, pipelined tiles, scheduling fences, explicit order files) are
+///  recorded in DESIGN.md and are no longer part of the lowering.
 //------------------------------------------------------------------------------
 #ifndef gfhip_options_hpp
 #define gfhip_options_hpp
@@ -37,8 +37,6 @@ struct codegen_options {
     uint32_t park_prefetch = 50;        ///< issue a reload this many nodes before its first use (< window)
     bool schedule_for_pressure = true;  ///< emit in the pressure-aware order of schedule.hpp (GFHIP_SCHEDULE=source: item order)
     int division_fixup = -1;            ///< v_div_fixup after each shared-reciprocal quotient: 1 yes, 0 no, -1 auto (GFHIP_DIV_FIXUP)
-    int prefetch_next_tile = -1;        ///< load the next grid-stride tile's inputs inside the pass: 1 yes, 0 no,
-                                        ///< -1 auto = items of up to 1500 nodes (GFHIP_PREFETCH)
 
 //  Environment overrides (they change the generated text, hence the cache key).
     static codegen_options from_environment() {
@@ -54,7 +52,6 @@ struct codegen_options {
         }
         if (const char *e = std::getenv("GFHIP_SCHEDULE")) o.schedule_for_pressure = std::string(e) != "source";
         if (const char *e = std::getenv("GFHIP_DIV_FIXUP")) o.division_fixup = std::string(e) != "0" ? 1 : 0;
-        if (const char *e = std::getenv("GFHIP_PREFETCH")) o.prefetch_next_tile = std::string(e) != "0" ? 1 : 0;
         if (const char *e = std::getenv("GFHIP_COMPACT_TABLES")) o.compact_tables = std::string(e) != "0";
         if (const char *e = std::getenv("GFHIP_POW")) o.pow_three_halves = std::string(e) != "libm";
         if (const char *e = std::getenv("GFHIP_WAVES_PER_SIMD")) o.waves_per_simd = static_cast<uint32_t> (std::atoi(e));
