@@ -13,6 +13,8 @@ WORKLOAD_DIR = os.path.join(HERE, "workloads")
 
 GFIR_F32 = 0
 GFIR_F64 = 1
+GFIR_C32 = 2
+GFIR_C64 = 3
 
 
 class KernelInfo(ctypes.Structure):
@@ -41,6 +43,7 @@ SYMBOLS = [
     ("gfhip_create_kernel_call", _I, [_P, _P, _P, _P, _P]),
     ("gfhip_run", _I, [_P, _U32]),
     ("gfhip_run_max", _I, [_P, ctypes.POINTER(ctypes.c_double)]),
+    ("gfhip_run_max_complex", _I, [_P, ctypes.POINTER(ctypes.c_double)]),
     ("gfhip_converge", _I, [_P, ctypes.c_double, _S, ctypes.POINTER(_S), ctypes.POINTER(ctypes.c_double)]),
     ("gfhip_converge_per_ray", _I, [_P, ctypes.c_double, _S, ctypes.POINTER(_S), ctypes.POINTER(ctypes.c_double)]),
     ("gfhip_wait", _I, [_P]),
@@ -48,6 +51,8 @@ SYMBOLS = [
     ("gfhip_copy_to_device", _I, [_P, _U64, _P]),
     ("gfhip_copy_to_host", _I, [_P, _U64, _P]),
     ("gfhip_check_value", _I, [_P, _U64, _S, ctypes.POINTER(ctypes.c_double)]),
+    ("gfhip_read_element", _I, [_P, _U64, _S, _P]),
+    ("gfhip_set_random_state", _I, [_P, _U64, _P, _S]),
     ("gfhip_get_buffer", _P, [_P, _U64, ctypes.POINTER(_S)]),
     ("gfhip_allocate_buffer", _I, [_P, _U64, _S, _U32]),
     ("gfhip_get_buffer_info", _I, [_P, _U64, ctypes.POINTER(_S), ctypes.POINTER(_U32)]),

@@ -96,7 +96,10 @@ struct kernel_writer {
     const bool use_shared;                          ///< shared-reciprocal division with the IEEE second body
     const std::vector<bool> &after_division;        ///< node depends on the result of a division
 
-    const bool f64 = it.dtype == GFIR_F64;
+    const bool f64 = it.base_is_f64();
+    const bool cx = it.is_complex();                ///< values are gf_complex (prelude.hpp)
+    const bool safe = it.safe_math();               ///< SAFE_MATH guards
+    const bool generic = cx || safe || it.has_random();     ///< operations go through the gf_* names
     const bool track_numerators = opt.division == division_mode::checked;
     const bool fixup = division_fixup(it, opt);
     const char *real = f64 ? "double" : "float";
@@ -116,6 +119,14 @@ struct kernel_writer {
             s = std::string("((") + real + ")" + (v != v ? "__builtin_nan(\"\")" : (v > 0 ? "__builtin_inf()" : "-__builtin_inf()")) + ")";
         }
         return s;
+    }
+
+//  A constant of the item's value type.
+    std::string value_literal(const double re, const double im = 0.0) const {
+        return cx ? "real(" + literal(re) + ", " + literal(im) + ")" : literal(re);
+    }
+    std::string call(const char *builtin, const char *generic_name) const {
+        return generic ? std::string(generic_name) : std::string(builtin) + sfx;
     }
 
 //  The node-for-node body.  `shared` = divisions through a reciprocal shared by all
@@ -148,7 +159,8 @@ struct kernel_writer {
                 s << "                vmax = __builtin_elementwise_maximum(vmax, gf_magnitude(" << quotient << "));\n";
                 e << quotient;
             } else {
-                e << "(" << N(arg) << " - " << literal(offset) << ")/" << literal(scale);
+                const std::string quotient = "(" + N(arg) + " - " + value_literal(offset) + ")/" + value_literal(scale);
+                e << (cx ? "gf_real(" + quotient + ")" : quotient);     // compile_index takes real(...) of a complex quotient
             }
             e << ", " << literal(0.0) << "), " << literal(static_cast<double> (length - 1)) << "))";
             return e.str();
@@ -202,7 +214,10 @@ struct kernel_writer {
             }
             switch (c.op) {
                 case GFIR_CONST:
-                    s << ind << "const real r" << i << " = " << literal(c.imm[0]) << ";\n";
+                    s << ind << "const real r" << i << " = " << value_literal(c.imm[0], c.imm[1]) << ";\n";
+                    break;
+                case GFIR_RANDOM:
+                    s << ind << "const real r" << i << " = gf_from_base(static_cast<base> (gf_random(random_state)));\n";
                     break;
                 case GFIR_INPUT:
                     s << ind << "const real r" << i << " = v" << c.a << ";\n";
@@ -214,7 +229,10 @@ struct kernel_writer {
                     s << ind << "const real r" << i << " = " << N(c.a) << " - " << N(c.b) << ";\n";
                     break;
                 case GFIR_MUL:
-                    s << ind << "const real r" << i << " = " << N(c.a) << "*" << N(c.b) << ";\n";
+//  SAFE_MATH: (l == 0 || r == 0) ? 0 : l*r, arithmetic.hpp:2534-2557
+                    s << ind << "const real r" << i << " = ";
+                    if (safe) s << "(" << N(c.a) << " == " << value_literal(0.0) << " || " << N(c.b) << " == " << value_literal(0.0) << ") ? " << value_literal(0.0) << " : ";
+                    s << N(c.a) << "*" << N(c.b) << ";\n";
                     break;
                 case GFIR_DIV:
                     if (shared) {
@@ -229,15 +247,20 @@ struct kernel_writer {
                         }
                         s << ind << "const real r" << i << " = gf_div(" << N(c.a) << ", " << N(c.b) << ", q" << c.b << ");\n";
                     } else {
-                        s << ind << "const real r" << i << " = " << N(c.a) << "/" << N(c.b) << ";\n";
+//  SAFE_MATH: l == 0 ? 0 : l/r, arithmetic.hpp:3526-3541
+                        s << ind << "const real r" << i << " = ";
+                        if (safe) s << N(c.a) << " == " << value_literal(0.0) << " ? " << value_literal(0.0) << " : ";
+                        s << N(c.a) << "/" << N(c.b) << ";\n";
                     }
                     break;
                 case GFIR_FMA:
-                    s << ind << "const real r" << i << " = __builtin_fma" << sfx << "(" << N(c.a) << ", " << N(c.b)
-                      << ", " << N(c.c) << ");\n";
+//  SAFE_MATH: (l == 0 || m == 0) ? r : fma(l, m, r), arithmetic.hpp:5101-5127
+                    s << ind << "const real r" << i << " = ";
+                    if (safe) s << "(" << N(c.a) << " == " << value_literal(0.0) << " || " << N(c.b) << " == " << value_literal(0.0) << ") ? " << N(c.c) << " : ";
+                    s << call("__builtin_fma", "gf_fma") << "(" << N(c.a) << ", " << N(c.b) << ", " << N(c.c) << ");\n";
                     break;
                 case GFIR_SQRT:
-                    s << ind << "const real r" << i << " = __builtin_sqrt" << sfx << "(" << N(c.a) << ");\n";
+                    s << ind << "const real r" << i << " = " << call("__builtin_sqrt", "gf_sqrt") << "(" << N(c.a) << ");\n";
                     break;
                 case GFIR_POWI: {
                     s << ind << "const real r" << i << " = " << N(c.a);
@@ -246,26 +269,33 @@ struct kernel_writer {
                     break;
                 }
                 case GFIR_POW:
-                    if (f64 && opt.pow_three_halves && it.code[c.b].op == GFIR_CONST && it.code[c.b].imm[0] == 1.5) {
+                    if (f64 && !generic && opt.pow_three_halves && it.code[c.b].op == GFIR_CONST && it.code[c.b].imm[0] == 1.5) {
                         s << ind << "const real r" << i << " = gf_pow_three_halves(" << N(c.a) << ");\n";
                     } else {
-                        s << ind << "const real r" << i << " = pow" << sfx << "(" << N(c.a) << ", " << N(c.b) << ");\n";
+                        s << ind << "const real r" << i << " = " << call("pow", "gf_pow") << "(" << N(c.a) << ", " << N(c.b) << ");\n";
                     }
                     break;
                 case GFIR_SIN:
-                    s << ind << "const real r" << i << " = sin" << sfx << "(" << N(c.a) << ");\n";
+                    s << ind << "const real r" << i << " = " << call("sin", "gf_sin") << "(" << N(c.a) << ");\n";
                     break;
                 case GFIR_COS:
-                    s << ind << "const real r" << i << " = cos" << sfx << "(" << N(c.a) << ");\n";
+                    s << ind << "const real r" << i << " = " << call("cos", "gf_cos") << "(" << N(c.a) << ");\n";
                     break;
                 case GFIR_ATAN2:
-                    s << ind << "const real r" << i << " = atan2" << sfx << "(" << N(c.b) << ", " << N(c.a) << ");\n";
+                    s << ind << "const real r" << i << " = " << call("atan2", "gf_atan2") << "(" << N(c.b) << ", " << N(c.a) << ");\n";
                     break;
                 case GFIR_EXP:
-                    s << ind << "const real r" << i << " = exp" << sfx << "(" << N(c.a) << ");\n";
+//  SAFE_MATH: real(x) < 709.8 ? exp(x) : the base type's largest value, math.hpp:450-471 (the
+//  reference prints that bound through an int-valued max_base(), an out-of-range conversion whose
+//  result is undefined; the intended value is used here)
+                    s << ind << "const real r" << i << " = ";
+                    if (safe) s << "gf_real(" << N(c.a) << ") < static_cast<base> (709.8) ? ";
+                    s << call("exp", "gf_exp") << "(" << N(c.a) << ")";
+                    if (safe) s << " : gf_from_base(" << (f64 ? "__DBL_MAX__" : "__FLT_MAX__") << ")";
+                    s << ";\n";
                     break;
                 case GFIR_LOG:
-                    s << ind << "const real r" << i << " = log" << sfx << "(" << N(c.a) << ");\n";
+                    s << ind << "const real r" << i << " = " << call("log", "gf_log") << "(" << N(c.a) << ");\n";
                     break;
                 case GFIR_GATHER1:
                 case GFIR_GATHER2: {
@@ -378,6 +408,7 @@ struct kernel_writer {
         for (size_t p = 0; p < out.packs.size(); p++) {
             s << "const real *__restrict__ pack" << p << ", ";
         }
+        if (it.has_random()) s << "gf_mt_state *__restrict__ random_states, ";
         s << "unsigned int *__restrict__ flags, const unsigned long long n, ";
         if (which == entry::converge) {
             s << "const real tolerance,\n        const unsigned int max_iterations, unsigned int *__restrict__ iterations) {\n";
@@ -424,6 +455,11 @@ struct kernel_writer {
         if (which == entry::max) {
             s << "    real lane_max = -__builtin_huge_val" << sfx << "();\n";
         }
+        if (it.has_random()) {
+//  cuda_context.hpp:509-522, :817: thread t of the (sequentially launched) blocks owns state t and
+//  draws for elements t, t + 1024, ... in that order; the launch has at most 1024 lanes (gf_hip.cpp).
+            s << "    gf_mt_state &random_state = random_states[blockIdx.x*blockDim.x + threadIdx.x];\n";
+        }
         s << "    for (unsigned long long i = blockIdx.x*static_cast<unsigned long long> (blockDim.x) + threadIdx.x; i < n;\n"
           << "         i += gridDim.x*static_cast<unsigned long long> (blockDim.x)) {\n";
         for (size_t i = 0; i < it.symbols.size(); i++) {
@@ -434,7 +470,7 @@ struct kernel_writer {
             s << "        real v" << i << " = in" << i << "[i];  // " << symbol << "\n";
         }
         for (size_t o = 0; o < it.outputs.size(); o++) {
-            s << "        real o" << o << " = " << literal(0.0) << ";\n";
+            s << "        real o" << o << " = " << value_literal(0.0) << ";\n";
         }
     }
 
@@ -519,11 +555,12 @@ struct kernel_writer {
             body(false);
             s << "            }\n";
         }
+//  SAFE_MATH stores isnan(x) ? 0 : x (per part for complex values), cpu_context.hpp:530-547.
         for (size_t o = 0; o < it.outputs.size(); o++) {
-            s << "            o" << o << " = so" << o << ";\n";
+            s << "            o" << o << " = " << (safe ? "gf_nan_to_zero(so" + std::to_string(o) + ")" : "so" + std::to_string(o)) << ";\n";
         }
         for (size_t k = 0; k < it.setters.size(); k++) {
-            s << "            v" << it.setters[k].input << " = sv" << k << ";\n";
+            s << "            v" << it.setters[k].input << " = " << (safe ? "gf_nan_to_zero(sv" + std::to_string(k) + ")" : "sv" + std::to_string(k)) << ";\n";
         }
         if (which == entry::converge) {
 //  converge_item::run for this ray:  while (A && B && C && iterations++ < max) {...}
@@ -615,8 +652,14 @@ inline lowered lower(const item &original, const codegen_options &opt = codegen_
     size_t lds_used = layout.lds_used;
     out.block_size = opt.block_size;
 
+//  Complex values, SAFE_MATH guards and random draws are off the hot path: no LDS parking, no
+//  shared reciprocals (guarded divisions may divide by zero on purpose), and the max of a complex
+//  output is the element of largest modulus, which reduce.hip finds.
+    const bool generic = it.is_complex() || it.safe_math() || it.has_random();
+    codegen_options plain = opt;
+    if (generic) plain.park_in_lds = false;
     uint32_t park_slots = 0;
-    const std::vector<park_plan> plan = plan_parking(it, opt, lds_used, esize, park_slots);
+    const std::vector<park_plan> plan = plan_parking(it, plain, lds_used, esize, park_slots);
     const size_t park_offset = lds_used;
     lds_used += static_cast<size_t> (park_slots)*opt.block_size*esize;
     out.lds_bytes = lds_used;
@@ -640,7 +683,7 @@ inline lowered lower(const item &original, const codegen_options &opt = codegen_
     emit_prelude(s, it, opt, out.packs.size());
 //  Items without a division node need neither the checks nor the second body (their gather
 //  indices then divide by the literal scale).
-    const bool use_shared = opt.division != division_mode::ieee && divides;
+    const bool use_shared = opt.division != division_mode::ieee && divides && !generic;
 //  Entry points: `<name>` runs `steps` passes.  Small items with an output also get `<name>_max`
 //  (the same, plus the max of the last output reduced inside the launch: create_max_call) and,
 //  with a setter, `<name>_converge`, which runs the stall loop of workflow.hpp:179-205 PER RAY
@@ -649,7 +692,7 @@ inline lowered lower(const item &original, const codegen_options &opt = codegen_
 //  each ray as its own shard; it equals the reference's global-max loop when the rays are
 //  identical (the benchmark) and is offered as gfhip_converge_per_ray.
     const bool small = it.code.size() <= 1500;
-    out.has_max = !it.outputs.empty() && small;
+    out.has_max = !it.outputs.empty() && small && !it.is_complex() && !it.has_random();
     out.has_converge = out.has_max && !it.setters.empty();
     kernel_writer writer{s, it, opt, out, parent, factor, table_pack, table_column, plan, lds_used, park_offset, park_slots,
                          use_shared, after_division};

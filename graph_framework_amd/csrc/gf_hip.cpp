@@ -16,6 +16,7 @@
 #include <sys/stat.h>
 
 #include <cmath>
+#include <complex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -35,6 +36,7 @@ namespace gfhip {
 void launch_max_reduce(const void *in, const size_t n, const bool f64,
                        unsigned long long *result, const unsigned int num_cus, hipStream_t stream);
 void launch_converge_decide(const bool f64, unsigned long long *reduced, void *state, hipStream_t stream);
+void launch_max_modulus(const void *in, const size_t n, const bool f64, void *result, hipStream_t stream);
 }
 
 namespace {
@@ -70,6 +72,10 @@ bool read_file(const std::string &path, std::vector<char> &data) {
     return static_cast<bool> (f);
 }
 
+size_t element_bytes(const uint32_t dtype) {
+    return gfhip::item::element_size(dtype);
+}
+
 std::string hash_name(const uint64_t hash) {
     char buf[32];
     std::snprintf(buf, sizeof(buf), "%016llx", static_cast<unsigned long long> (hash));
@@ -84,6 +90,7 @@ struct gfhip_context {
     bool own_stream = false;
     unsigned int num_cus = 256;
     std::map<uint64_t, buffer> buffers;
+    std::map<uint64_t, std::pair<void *, size_t>> random_states;    // MT19937 states per random_state node (raw bytes)
     std::vector<std::unique_ptr<gfhip_kernel>> kernels;
     std::string error;
     unsigned long long *device_scalar = nullptr;
@@ -118,6 +125,7 @@ struct gfhip_kernel {
     bool from_cache = false;
     std::vector<void *> pack_device;
     std::vector<uint64_t> input_keys, output_keys;
+    void *random_states = nullptr;                 // device copy of the item's random_state node (items with draws)
     bool bound = false;
     unsigned int grid = 1;
     int vgprs = 0, sgprs = 0, lds_static = 0, scratch = 0;
@@ -210,6 +218,9 @@ extern "C" void gfhip_destroy_context(gfhip_context *ctx) {
     for (auto &kv : ctx->buffers) {
         if (kv.second.owned && kv.second.pointer) (void)hipFree(kv.second.pointer);
         if (kv.second.mirror) (void)hipHostFree(kv.second.mirror);
+    }
+    for (auto &kv : ctx->random_states) {
+        if (kv.second.first) (void)hipFree(kv.second.first);
     }
     if (ctx->device_converge) (void)hipFree(ctx->device_converge);
     if (ctx->host_converge) (void)hipHostFree(ctx->host_converge);
@@ -330,6 +341,8 @@ static int build_kernel(gfhip_context *ctx, gfhip_kernel *k) {
 
 //  Pack and upload the tables: [cell][column], padded to the pack stride.
     const size_t esize = k->item.element_size();
+    const size_t parts = k->item.is_complex() ? 2 : 1;
+    const bool wide = k->item.base_is_f64();
     for (size_t p = 0; p < k->low.packs.size(); p++) {
         const gfhip::pack &pk = k->low.packs[p];
         const size_t cells = pk.cells();
@@ -337,10 +350,13 @@ static int build_kernel(gfhip_context *ctx, gfhip_kernel *k) {
         for (size_t column = 0; column < pk.tables.size(); column++) {
             const gfhip::table &t = k->item.tables[pk.tables[column]];
             for (size_t cell = 0; cell < cells; cell++) {
-                if (esize == 8) {
-                    reinterpret_cast<double *> (host.data())[cell*pk.stride + column] = t.data[cell];
-                } else {
-                    reinterpret_cast<float *> (host.data())[cell*pk.stride + column] = static_cast<float> (t.data[cell]);
+                for (size_t part = 0; part < parts; part++) {
+                    const size_t at = (cell*pk.stride + column)*parts + part;
+                    if (wide) {
+                        reinterpret_cast<double *> (host.data())[at] = t.data[cell*parts + part];
+                    } else {
+                        reinterpret_cast<float *> (host.data())[at] = static_cast<float> (t.data[cell*parts + part]);
+                    }
                 }
             }
         }
@@ -378,6 +394,10 @@ static int build_kernel(gfhip_context *ctx, gfhip_kernel *k) {
     k->scratch = scratch;
     k->from_cache = from_cache;
     k->grid = static_cast<unsigned int> (want < cap ? want : cap);
+//  A kernel that draws random numbers: lane t owns MT19937 state t of 1024 and serves elements
+//  t, t + 1024, ... in order (cuda_context.hpp:509-522 launches one 1024-thread block per 1024
+//  elements, one after the other).
+    if (k->item.has_random() && k->grid*block > 1024) k->grid = static_cast<unsigned int> (1024/block);
     k->built = true;
     return 0;
 }
@@ -400,7 +420,7 @@ static int ensure_buffer(gfhip_context *ctx, const uint64_t key, const size_t co
         buffer b;
         b.count = count;
         b.dtype = dtype;
-        const size_t esize = dtype == GFIR_F32 ? 4 : 8;
+        const size_t esize = element_bytes(dtype);
         const size_t bytes = count*esize;
         if (init_count > count) init_count = count;
         GFHIP_TRY(ctx, hipMalloc(&b.pointer, bytes ? bytes : 8), "hipMalloc(buffer)");
@@ -479,6 +499,10 @@ static int launch(gfhip_kernel *k, const uint32_t steps, unsigned long long *red
     for (auto key : k->input_keys) pointers.push_back(ctx->buffers[key].pointer);
     for (auto key : k->output_keys) pointers.push_back(ctx->buffers[key].pointer);
     for (void *p : k->pack_device) pointers.push_back(p);
+    if (k->item.has_random()) {
+        if (!k->random_states) return ctx->fail("the item draws random numbers but no random state is bound (gfhip_set_random_state)");
+        pointers.push_back(k->random_states);
+    }
     pointers.push_back(ctx->device_flags);
     unsigned long long n = k->num_rays;
     unsigned int step_count = steps;
@@ -548,11 +572,43 @@ static int enqueue_pass_with_max(gfhip_kernel *k, const unsigned int *stop) {
     return 0;
 }
 
+//  Complex items: run, then the element of largest modulus of the last output, as
+//  cpu_context.hpp:314-318 selects it (std::max_element on std::abs, the first of equals).
+extern "C" int gfhip_run_max_complex(gfhip_kernel *k, double *value) {
+    if (!k || !value) return 1;
+    gfhip_context *ctx = k->ctx;
+    GFHIP_TRY(ctx, hipSetDevice(ctx->device), "hipSetDevice");
+    if (k->output_keys.empty()) return ctx->fail("converge item has no output to reduce");
+    if (!k->item.is_complex()) {
+        value[1] = 0.0;
+        return gfhip_run_max(k, value);
+    }
+    if (launch(k, 1)) return 1;
+    value[0] = value[1] = 0.0;
+    if (k->num_rays == 0) return 0;
+    const buffer &b = ctx->buffers[k->output_keys.back()];
+    const bool wide = k->item.base_is_f64();
+    gfhip::launch_max_modulus(b.pointer, k->num_rays, wide, ctx->device_converge, ctx->stream);
+    GFHIP_TRY(ctx, hipGetLastError(), "max_modulus launch");
+    GFHIP_TRY(ctx, hipMemcpyAsync(ctx->host_converge, ctx->device_converge, 16, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
+    GFHIP_TRY(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    if (wide) {
+        std::memcpy(value, ctx->host_converge, 16);
+    } else {
+        float narrow[2];
+        std::memcpy(narrow, ctx->host_converge, 8);
+        value[0] = narrow[0];
+        value[1] = narrow[1];
+    }
+    return 0;
+}
+
 extern "C" int gfhip_run_max(gfhip_kernel *k, double *max_value) {
     if (!k) return 1;
     gfhip_context *ctx = k->ctx;
     GFHIP_TRY(ctx, hipSetDevice(ctx->device), "hipSetDevice");
     if (k->output_keys.empty()) return ctx->fail("converge item has no output to reduce");
+    if (k->item.is_complex()) return ctx->fail("complex item: use gfhip_run_max_complex");
     GFHIP_TRY(ctx, hipMemsetAsync(ctx->device_scalar, 0, sizeof(unsigned long long), ctx->stream), "hipMemsetAsync");
     if (enqueue_pass_with_max(k, nullptr)) return 1;
     GFHIP_TRY(ctx, hipMemcpyAsync(ctx->host_scalar, ctx->device_scalar, sizeof(unsigned long long),
@@ -588,6 +644,35 @@ static int converge_loop(gfhip_kernel *k, const double tolerance_, const size_t 
     }
     if (iterations_out) *iterations_out = iterations;
     if (last_max) *last_max = static_cast<double> (max_residual);
+    return 0;
+}
+
+//  ... for complex items (max = the element of largest modulus; the loop compares moduli,
+//  workflow.hpp:183-186 with T = std::complex).
+template<typename B>
+static int converge_loop_complex(gfhip_kernel *k, const double tolerance_, const size_t max_iterations,
+                                 size_t *iterations_out, double *last_max) {
+    typedef std::complex<B> T;
+    const T tolerance(static_cast<B> (tolerance_), 0);
+    size_t iterations = 0;
+    double value[2];
+    if (gfhip_run_max_complex(k, value)) return 1;
+    T max_residual(static_cast<B> (value[0]), static_cast<B> (value[1]));
+    T last = std::numeric_limits<T>::max();            // std::numeric_limits<std::complex> is the unspecialised one: T()
+    T off_last = std::numeric_limits<T>::max();
+    while (std::abs(max_residual) > std::abs(tolerance)            &&
+           std::abs(last - max_residual) > std::abs(tolerance)     &&
+           std::abs(off_last - max_residual) > std::abs(tolerance) &&
+           iterations++ < max_iterations) {
+        last = max_residual;
+        if (!(iterations%2)) {
+            off_last = max_residual;
+        }
+        if (gfhip_run_max_complex(k, value)) return 1;
+        max_residual = T(static_cast<B> (value[0]), static_cast<B> (value[1]));
+    }
+    if (iterations_out) *iterations_out = iterations;
+    if (last_max) *last_max = static_cast<double> (std::abs(max_residual));
     return 0;
 }
 
@@ -654,7 +739,10 @@ extern "C" int gfhip_converge(gfhip_kernel *k, double tolerance, size_t max_iter
     size_t used = 0;
     double residual = 0.0;
     int status;
-    if (k->max_function && k->num_rays > 0) {
+    if (k->item.is_complex()) {
+        status = k->item.base_is_f64() ? converge_loop_complex<double> (k, tolerance, max_iterations, &used, &residual)
+                                       : converge_loop_complex<float> (k, tolerance, max_iterations, &used, &residual);
+    } else if (k->max_function && k->num_rays > 0) {
         status = converge_on_device(k, tolerance, max_iterations, &used, &residual);
     } else if (k->item.dtype == GFIR_F64) {
         status = converge_loop<double> (k, tolerance, max_iterations, &used, &residual);
@@ -733,7 +821,7 @@ extern "C" int gfhip_wait(gfhip_context *ctx) {
     for (auto &kv : ctx->buffers) {
         buffer &b = kv.second;
         if (b.mirror && b.count) {
-            GFHIP_TRY(ctx, hipMemcpyAsync(b.mirror, b.pointer, b.count*(b.dtype == GFIR_F32 ? 4 : 8),
+            GFHIP_TRY(ctx, hipMemcpyAsync(b.mirror, b.pointer, b.count*element_bytes(b.dtype),
                                           hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync(mirror)");
         }
     }
@@ -763,7 +851,7 @@ extern "C" int gfhip_copy_to_device(gfhip_context *ctx, uint64_t key, const void
     buffer *b = find_buffer(ctx, key);
     if (!b) return 1;
     GFHIP_TRY(ctx, hipSetDevice(ctx->device), "hipSetDevice");
-    GFHIP_TRY(ctx, hipMemcpyAsync(b->pointer, host, b->count*(b->dtype == GFIR_F32 ? 4 : 8),
+    GFHIP_TRY(ctx, hipMemcpyAsync(b->pointer, host, b->count*element_bytes(b->dtype),
                                   hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync(H2D)");
     GFHIP_TRY(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
     return 0;
@@ -774,28 +862,56 @@ extern "C" int gfhip_copy_to_host(gfhip_context *ctx, uint64_t key, void *host) 
     buffer *b = find_buffer(ctx, key);
     if (!b) return 1;
     GFHIP_TRY(ctx, hipSetDevice(ctx->device), "hipSetDevice");
-    GFHIP_TRY(ctx, hipMemcpyAsync(host, b->pointer, b->count*(b->dtype == GFIR_F32 ? 4 : 8),
+    GFHIP_TRY(ctx, hipMemcpyAsync(host, b->pointer, b->count*element_bytes(b->dtype),
                                   hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync(D2H)");
     GFHIP_TRY(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
     return 0;
 }
 
-extern "C" int gfhip_check_value(gfhip_context *ctx, uint64_t key, size_t index, double *value) {
-    if (!ctx) return 1;
+extern "C" int gfhip_read_element(gfhip_context *ctx, uint64_t key, size_t index, void *element) {
+    if (!ctx || !element) return 1;
     buffer *b = find_buffer(ctx, key);
     if (!b) return 1;
     if (index >= b->count) return ctx->fail("index out of range");
     GFHIP_TRY(ctx, hipSetDevice(ctx->device), "hipSetDevice");
     GFHIP_TRY(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
-    if (b->dtype == GFIR_F64) {
-        double v;
-        GFHIP_TRY(ctx, hipMemcpy(&v, static_cast<double *> (b->pointer) + index, 8, hipMemcpyDeviceToHost), "hipMemcpy");
-        *value = v;
-    } else {
-        float v;
-        GFHIP_TRY(ctx, hipMemcpy(&v, static_cast<float *> (b->pointer) + index, 4, hipMemcpyDeviceToHost), "hipMemcpy");
-        *value = v;
+    const size_t esize = element_bytes(b->dtype);
+    GFHIP_TRY(ctx, hipMemcpy(element, static_cast<char *> (b->pointer) + index*esize, esize, hipMemcpyDeviceToHost), "hipMemcpy");
+    return 0;
+}
+
+extern "C" int gfhip_check_value(gfhip_context *ctx, uint64_t key, size_t index, double *value) {
+    if (!ctx || !value) return 1;
+    double parts[2] = {0.0, 0.0};
+    float narrow[2] = {0.0f, 0.0f};
+    buffer *b = find_buffer(ctx, key);
+    if (!b) return 1;
+    const bool wide = b->dtype == GFIR_F64 || b->dtype == GFIR_C64;
+    if (gfhip_read_element(ctx, key, index, wide ? static_cast<void *> (parts) : static_cast<void *> (narrow))) return 1;
+    *value = wide ? parts[0] : static_cast<double> (narrow[0]);        // the real part of a complex element
+    return 0;
+}
+
+extern "C" int gfhip_set_random_state(gfhip_kernel *k, uint64_t key, const void *states, size_t bytes) {
+    if (!k) return 1;
+    gfhip_context *ctx = k->ctx;
+    if (!k->item.has_random()) return 0;
+//  The kernel indexes 1024 states of 2500 bytes (random.hpp:44-52 without the CUDA padding).
+    const size_t needed = 1024*2500;
+    if (!states || bytes < needed) return ctx->fail("a random state of 1024 MT19937 states (2500 bytes each) is required");
+    GFHIP_TRY(ctx, hipSetDevice(ctx->device), "hipSetDevice");
+    auto found = ctx->random_states.find(key);
+    if (found == ctx->random_states.end()) {
+        void *device = nullptr;
+        GFHIP_TRY(ctx, hipMalloc(&device, bytes), "hipMalloc(random state)");
+        const hipError_t status = hipMemcpy(device, states, bytes, hipMemcpyHostToDevice);
+        if (status != hipSuccess) {
+            (void)hipFree(device);
+            return ctx->check(status, "hipMemcpy(random state)");
+        }
+        found = ctx->random_states.insert({key, {device, bytes}}).first;
     }
+    k->random_states = found->second.first;
     return 0;
 }
 
@@ -809,7 +925,7 @@ extern "C" void *gfhip_get_buffer(gfhip_context *ctx, uint64_t key, size_t *coun
 
 extern "C" int gfhip_allocate_buffer(gfhip_context *ctx, uint64_t key, size_t count, uint32_t dtype) {
     if (!ctx) return 1;
-    if (dtype != GFIR_F32 && dtype != GFIR_F64) return ctx->fail("bad dtype");
+    if (dtype > GFIR_C64) return ctx->fail("bad dtype");
     GFHIP_TRY(ctx, hipSetDevice(ctx->device), "hipSetDevice");
     return ensure_buffer(ctx, key, count, dtype, nullptr);
 }
@@ -828,7 +944,7 @@ extern "C" void *gfhip_get_host_buffer(gfhip_context *ctx, uint64_t key, size_t 
     buffer *b = find_buffer(ctx, key);
     if (!b) return nullptr;
     if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
-    const size_t bytes = b->count*(b->dtype == GFIR_F32 ? 4 : 8);
+    const size_t bytes = b->count*element_bytes(b->dtype);
     if (!b->mirror) {
         if (ctx->check(hipHostMalloc(&b->mirror, bytes ? bytes : 8, hipHostMallocDefault), "hipHostMalloc(mirror)")) {
             b->mirror = nullptr;
@@ -846,7 +962,7 @@ extern "C" void *gfhip_get_host_buffer(gfhip_context *ctx, uint64_t key, size_t 
 extern "C" int gfhip_set_buffer(gfhip_context *ctx, uint64_t key, void *device_pointer, size_t count, uint32_t dtype) {
     if (!ctx) return 1;
     if (!device_pointer && count) return ctx->fail("null device pointer");
-    if (dtype != GFIR_F32 && dtype != GFIR_F64) return ctx->fail("bad dtype");
+    if (dtype > GFIR_C64) return ctx->fail("bad dtype");
     auto found = ctx->buffers.find(key);
     if (found != ctx->buffers.end()) {
         if (found->second.owned && found->second.pointer) (void)hipFree(found->second.pointer);

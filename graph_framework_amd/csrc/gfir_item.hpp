@@ -17,11 +17,12 @@ namespace gfhip {
 
 struct table {
     uint32_t rows, cols;
-    std::vector<double> data;
+    std::vector<double> data;               ///< rows*cols values (complex items: (re, im) pairs)
 };
 
 struct item {
     uint32_t dtype = GFIR_F64;
+    uint32_t flags = 0;                     ///< GFIR_SAFE_MATH
     std::string name;
     std::vector<std::string> symbols;       ///< one per input, kernel argument order
     std::vector<table> tables;
@@ -29,8 +30,18 @@ struct item {
     std::vector<uint32_t> outputs;
     std::vector<gfir_setter> setters;
 
-    size_t element_size() const {
-        return dtype == GFIR_F32 ? 4 : 8;
+    static size_t element_size(const uint32_t dtype) {
+        return dtype == GFIR_F32 ? 4 : dtype == GFIR_C64 ? 16 : 8;
+    }
+    size_t element_size() const { return element_size(dtype); }
+    bool is_complex() const { return dtype == GFIR_C32 || dtype == GFIR_C64; }
+    bool base_is_f64() const { return dtype == GFIR_F64 || dtype == GFIR_C64; }
+    bool safe_math() const { return flags & GFIR_SAFE_MATH; }
+    bool has_random() const {
+        for (auto &c : code) {
+            if (c.op == GFIR_RANDOM) return true;
+        }
+        return false;
     }
 
 ///  Elements an index node reads of input `i`'s buffer (0 if none does): the buffer bound to
@@ -73,11 +84,17 @@ struct item {
             error = "not a GFIR item (bad magic)";
             return false;
         }
-        if (h.dtype != GFIR_F32 && h.dtype != GFIR_F64) {
+        if (h.dtype > GFIR_C64) {
             error = "unsupported GFIR dtype";
             return false;
         }
+        if (h.flags & ~GFIR_SAFE_MATH) {
+            error = "unknown GFIR flags";
+            return false;
+        }
         dtype = h.dtype;
+        flags = h.flags;
+        const size_t parts = is_complex() ? 2 : 1;
 //  Every count is bounded by the bytes that remain, before anything is allocated.
         if (h.name_bytes > bytes || h.num_inputs > bytes/4 || h.num_tables > bytes/8 ||
             h.num_instructions > bytes/sizeof(gfir_instruction) || h.num_outputs > bytes/4 ||
@@ -124,11 +141,11 @@ struct item {
                 error = "empty table in GFIR item";
                 return false;
             }
-            if (static_cast<size_t> (th.rows)*th.cols > bytes/sizeof(double)) {
+            if (static_cast<size_t> (th.rows)*th.cols > bytes/sizeof(double)/parts) {
                 error = "GFIR item is truncated";
                 return false;
             }
-            t.data.resize(static_cast<size_t> (th.rows)*th.cols);
+            t.data.resize(static_cast<size_t> (th.rows)*th.cols*parts);
             if (!take(t.data.data(), sizeof(double)*t.data.size())) return false;
         }
 
@@ -158,6 +175,7 @@ struct item {
                     ok = before(c.a) && c.aux < h.num_tables && tables[c.aux].rows == 1; break;
                 case GFIR_GATHER2:
                     ok = before(c.a) && before(c.b) && c.aux < h.num_tables; break;
+                case GFIR_RANDOM: ok = before(c.a); break;
                 case GFIR_INDEX1:
                     ok = before(c.a) && c.c < h.num_inputs && c.aux >= 1; break;
                 case GFIR_INDEX2:

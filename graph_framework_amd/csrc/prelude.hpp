@@ -53,15 +53,133 @@ inline bool division_fixup(const item &it, const codegen_options &opt) {
     return false;
 }
 
+//  Complex base types (graph_type COMPLEX_FLOAT / COMPLEX_DOUBLE).  The reference's kernels use
+//  std::complex with the host compiler's operators (cpu_context.hpp:428-584), i.e. whatever
+//  __muldc3/__divdc3 the JIT links; no fixture pins them ("parity unpinned").  Here:
+//  the textbook product, Smith's quotient (libgcc's classic __divdc3 without its NaN recovery),
+//  every operation unfused; elementary functions through their real parts' formulas.
+inline void emit_complex(std::ostringstream &s, const bool f64) {
+    const std::string x = f64 ? "" : "f";
+    s << R"(
+struct gf_complex {
+    base re, im;
+    __device__ __forceinline__ gf_complex() : re(0), im(0) {}
+    __device__ __forceinline__ gf_complex(const base r, const base i) : re(r), im(i) {}
+};
+__device__ __forceinline__ gf_complex operator+(const gf_complex a, const gf_complex b) { return gf_complex(a.re + b.re, a.im + b.im); }
+__device__ __forceinline__ gf_complex operator-(const gf_complex a, const gf_complex b) { return gf_complex(a.re - b.re, a.im - b.im); }
+__device__ __forceinline__ gf_complex operator*(const gf_complex a, const gf_complex b) {
+    return gf_complex(a.re*b.re - a.im*b.im, a.re*b.im + a.im*b.re);
+}
+__device__ __forceinline__ gf_complex operator/(const gf_complex a, const gf_complex b) {
+    if (__builtin_fabs)" << x << R"((b.re) < __builtin_fabs)" << x << R"((b.im)) {
+        const base ratio = b.re/b.im, denom = b.re*ratio + b.im;
+        return gf_complex((a.re*ratio + a.im)/denom, (a.im*ratio - a.re)/denom);
+    }
+    const base ratio = b.im/b.re, denom = b.im*ratio + b.re;
+    return gf_complex((a.im*ratio + a.re)/denom, (a.im - a.re*ratio)/denom);
+}
+__device__ __forceinline__ bool operator==(const gf_complex a, const gf_complex b) { return a.re == b.re && a.im == b.im; }
+__device__ __forceinline__ base gf_real(const gf_complex a) { return a.re; }
+__device__ __forceinline__ gf_complex gf_fma(const gf_complex a, const gf_complex b, const gf_complex c) { return a*b + c; }   // arithmetic.hpp:5118-5121
+__device__ __forceinline__ gf_complex gf_exp(const gf_complex a) {
+    const base e = exp)" << x << R"((a.re);
+    return gf_complex(e*cos)" << x << R"((a.im), e*sin)" << x << R"((a.im));
+}
+__device__ __forceinline__ gf_complex gf_log(const gf_complex a) {
+    return gf_complex(log)" << x << R"((hypot)" << x << R"((a.re, a.im)), atan2)" << x << R"((a.im, a.re));
+}
+__device__ __forceinline__ gf_complex gf_sqrt(const gf_complex a) {
+    if (a.re == 0 && a.im == 0) return gf_complex(0, a.im);
+    const base m = hypot)" << x << R"((a.re, a.im);
+    if (a.re >= 0) {
+        const base t = __builtin_sqrt)" << x << R"(((m + a.re)*static_cast<base> (0.5));
+        return gf_complex(t, a.im/(t + t));
+    }
+    const base t = __builtin_sqrt)" << x << R"(((m - a.re)*static_cast<base> (0.5));
+    return gf_complex(__builtin_fabs)" << x << R"((a.im)/(t + t), a.im < 0 ? -t : t);
+}
+__device__ __forceinline__ gf_complex gf_pow(const gf_complex a, const gf_complex b) {
+    if (a.re == 0 && a.im == 0) return (b.re == 0 && b.im == 0) ? gf_complex(1, 0) : gf_complex(0, 0);
+    return gf_exp(b*gf_log(a));
+}
+__device__ __forceinline__ gf_complex gf_sin(const gf_complex a) {
+    return gf_complex(sin)" << x << R"((a.re)*cosh)" << x << R"((a.im), cos)" << x << R"((a.re)*sinh)" << x << R"((a.im));
+}
+__device__ __forceinline__ gf_complex gf_cos(const gf_complex a) {
+    return gf_complex(cos)" << x << R"((a.re)*cosh)" << x << R"((a.im), -sin)" << x << R"((a.re)*sinh)" << x << R"((a.im));
+}
+// atan(z) = (i/2) log((i + z)/(i - z)); the reference emits atan(right/left) for complex types (trigonometry.hpp:718-722)
+__device__ __forceinline__ gf_complex gf_atan2(const gf_complex r, const gf_complex l) {
+    const gf_complex z = r/l, i(0, 1);
+    const gf_complex w = gf_log((i + z)/(i - z));
+    return gf_complex(-w.im*static_cast<base> (0.5), w.re*static_cast<base> (0.5));
+}
+__device__ __forceinline__ gf_complex gf_nan_to_zero(const gf_complex a) {        // cpu_context.hpp:530-537
+    return gf_complex(a.re != a.re ? static_cast<base> (0) : a.re, a.im != a.im ? static_cast<base> (0) : a.im);
+}
+__device__ __forceinline__ gf_complex gf_from_base(const base a) { return gf_complex(a, 0); }
+)";
+}
+
+//  What items with complex values, SAFE_MATH guards or a random state call by name (the plain
+//  real-valued hot path keeps the builtins in its text).
+inline void emit_generic(std::ostringstream &s, const item &it, const bool f64) {
+    const std::string x = f64 ? "" : "f";
+    s << R"(
+__device__ __forceinline__ base gf_real(const base a) { return a; }
+__device__ __forceinline__ base gf_fma(const base a, const base b, const base c) { return __builtin_fma)" << x << R"((a, b, c); }
+__device__ __forceinline__ base gf_sqrt(const base a) { return __builtin_sqrt)" << x << R"((a); }
+__device__ __forceinline__ base gf_exp(const base a) { return exp)" << x << R"((a); }
+__device__ __forceinline__ base gf_log(const base a) { return log)" << x << R"((a); }
+__device__ __forceinline__ base gf_pow(const base a, const base b) { return pow)" << x << R"((a, b); }
+__device__ __forceinline__ base gf_sin(const base a) { return sin)" << x << R"((a); }
+__device__ __forceinline__ base gf_cos(const base a) { return cos)" << x << R"((a); }
+__device__ __forceinline__ base gf_atan2(const base r, const base l) { return atan2)" << x << R"((r, l); }
+__device__ __forceinline__ base gf_nan_to_zero(const base a) { return a != a ? static_cast<base> (0) : a; }          // cpu_context.hpp:538-541
+)";
+    if (!it.is_complex()) s << "__device__ __forceinline__ base gf_from_base(const base a) { return a; }\n";
+    if (it.has_random()) {
+//  random_state_node::mt_state and random_node::compile_random (random.hpp:44-52, :318-339):
+//  MT19937 advanced one word per draw.
+        s << R"(
+struct gf_mt_state { unsigned int array[624]; unsigned short index; };
+__device__ inline unsigned int gf_random(gf_mt_state &state) {
+    const unsigned short k = state.index;
+    unsigned short j = (k + 1)%624;
+    unsigned int x = (state.array[k] & 0x80000000u) | (state.array[j] & 0x7fffffffu);
+    unsigned int xa = x >> 1;
+    if (x & 1u) xa ^= 0x9908b0dfu;
+    j = (k + 397)%624;
+    x = state.array[j]^xa;
+    state.array[k] = x;
+    state.index = (k + 1)%624;
+    unsigned int y = x^(x >> 11);
+    y = y^((y << 7) & 0x9d2c5680u);
+    y = y^((y << 15) & 0xefc60000u);
+    return y^(y >> 18);
+}
+)";
+    }
+}
+
 inline void emit_prelude(std::ostringstream &s, const item &it, const codegen_options &opt, const size_t pack_count) {
-    const bool f64 = it.dtype == GFIR_F64;
-    const char *real = f64 ? "double" : "float";
+    const bool f64 = it.base_is_f64();
+    const char *base = f64 ? "double" : "float";
     s << "// Generated by graph_framework_amd (GFIR -> gfx950).  Work item \"" << it.name << "\": "
       << it.code.size() << " nodes, " << it.tables.size() << " tables in " << pack_count << " packs.\n";
 //  hipRTC predefines the runtime declarations; its include search does not always reach the
 //  ROCm headers (a stand-alone process on a box whose /opt/rocm hipRTC has no header path).
     s << "#if !defined(__HIPCC_RTC__)\n#include <hip/hip_runtime.h>\n#endif\n";
-    s << "typedef " << real << " real;\n";
+    s << "typedef " << base << " base;\n";
+    if (it.is_complex()) {
+        emit_complex(s, f64);
+        s << "typedef gf_complex real;\n";
+    } else {
+        s << "typedef base real;\n";
+    }
+    if (it.is_complex() || it.safe_math() || it.has_random()) emit_generic(s, it, f64);
+    if (it.is_complex()) return;
     const bool fixup = division_fixup(it, opt);
 //  Window check of the denominators: |d| is tracked through an fp32 image that is monotonic in
 //  |d| — |d| itself for float, the high dword of a double read as a float (sign, 11 exponent

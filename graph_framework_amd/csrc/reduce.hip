@@ -135,6 +135,57 @@ void launch_converge_decide(const bool f64, unsigned long long *reduced, void *s
     }
 }
 
+//  Complex outputs: the element of largest modulus, the first of equals — std::max_element with
+//  std::abs as cpu_context.hpp:314-318 calls it (one workgroup, as cuda_context.hpp:954-995).
+template<typename T> struct complex_pair { T re, im; };
+
+template<typename T>
+__global__ void __launch_bounds__(1024)
+max_modulus_kernel(const complex_pair<T> *__restrict__ in, const unsigned long long n, complex_pair<T> *__restrict__ result) {
+    T best = -1;
+    unsigned long long where = n;
+    for (unsigned long long i = threadIdx.x; i < n; i += blockDim.x) {
+        const T modulus = sizeof(T) == 8 ? static_cast<T> (hypot(static_cast<double> (in[i].re), static_cast<double> (in[i].im)))
+                                         : static_cast<T> (hypotf(static_cast<float> (in[i].re), static_cast<float> (in[i].im)));
+        if (modulus > best) {                          // strictly greater: the first of equals stays
+            best = modulus;
+            where = i;
+        }
+    }
+    __shared__ T moduli[1024];
+    __shared__ unsigned long long places[1024];
+    moduli[threadIdx.x] = best;
+    places[threadIdx.x] = where;
+    __syncthreads();
+    for (unsigned int half = 512; half > 0; half >>= 1) {
+        if (threadIdx.x < half) {
+            const T other = moduli[threadIdx.x + half];
+            const unsigned long long place = places[threadIdx.x + half];
+            if (other > moduli[threadIdx.x] || (other == moduli[threadIdx.x] && place < places[threadIdx.x])) {
+                moduli[threadIdx.x] = other;
+                places[threadIdx.x] = place;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+//  std::max_element keeps element 0 when every comparison is false (all moduli NaN).
+        *result = in[places[0] < n ? places[0] : 0];
+    }
+}
+
+void launch_max_modulus(const void *in, const size_t n, const bool f64, void *result, hipStream_t stream) {
+    if (f64) {
+        hipLaunchKernelGGL(max_modulus_kernel<double>, dim3(1), dim3(1024), 0, stream,
+                           static_cast<const complex_pair<double> *> (in), static_cast<unsigned long long> (n),
+                           static_cast<complex_pair<double> *> (result));
+    } else {
+        hipLaunchKernelGGL(max_modulus_kernel<float>, dim3(1), dim3(1024), 0, stream,
+                           static_cast<const complex_pair<float> *> (in), static_cast<unsigned long long> (n),
+                           static_cast<complex_pair<float> *> (result));
+    }
+}
+
 void launch_max_reduce(const void *in, const size_t n, const bool f64,
                        unsigned long long *result, const unsigned int num_cus, hipStream_t stream) {
     const unsigned int block = 256;

@@ -51,7 +51,7 @@ inline table_layout layout_tables(const item &it, const codegen_options &opt) {
     std::vector<double> &factor = layout.factor;
     parent.assign(it.tables.size(), -1);
     factor.assign(it.tables.size(), 1.0);
-    if (opt.compact_tables) {
+    if (opt.compact_tables && !it.is_complex()) {
         auto derive = [&] (const table &from, const table &to, double &k_out) -> bool {
             if (from.rows != to.rows || from.cols != to.cols) return false;
             size_t arg = 0;

@@ -47,6 +47,24 @@ private:
     };
     std::vector<table> tables;
 
+    static double real_part(const T value) {
+        if constexpr (jit::complex_scalar<T>) {
+            return static_cast<double> (std::real(value));
+        } else {
+            return static_cast<double> (value);
+        }
+    }
+    static double imaginary_part(const T value) {
+        if constexpr (jit::complex_scalar<T>) {
+            return static_cast<double> (std::imag(value));
+        } else {
+            return 0.0;
+        }
+    }
+
+///  The latest draw (GFIR_RANDOM) or the token the first draw hangs on: orders the draws.
+    uint32_t last_draw = GFIR_NONE;
+
     uint32_t emit(const gfir_instruction &i) {
         code.push_back(i);
         return static_cast<uint32_t> (code.size() - 1);
@@ -66,9 +84,17 @@ private:
         table t;
         t.rows = rows;
         t.cols = cols;
-        t.data.resize(b.size());
-        for (size_t i = 0, ie = b.size(); i < ie; i++) {
-            t.data[i] = static_cast<double> (b[i]);
+        if constexpr (jit::complex_scalar<T>) {
+            t.data.resize(2*b.size());
+            for (size_t i = 0, ie = b.size(); i < ie; i++) {
+                t.data[2*i] = real_part(b[i]);
+                t.data[2*i + 1] = imaginary_part(b[i]);
+            }
+        } else {
+            t.data.resize(b.size());
+            for (size_t i = 0, ie = b.size(); i < ie; i++) {
+                t.data[i] = static_cast<double> (b[i]);
+            }
         }
         for (size_t i = 0, ie = tables.size(); i < ie; i++) {
             if (tables[i].rows == rows && tables[i].cols == cols &&
@@ -81,6 +107,11 @@ private:
     }
 
     uint32_t lower(graph::shared_leaf<T, SAFE_MATH> n) {
+//  random_node::compile registers the TEXT `random(state)` (random.hpp:418): every use of the node
+//  is a draw of its own, so it is never looked up.
+        if (auto r = graph::random_cast(n); r.get()) {
+            return draw();
+        }
         auto found = slots.find(n.get());
         if (found != slots.end()) {
             return found->second;
@@ -88,7 +119,9 @@ private:
         uint32_t slot = GFIR_NONE;
         if (auto c = graph::constant_cast(n); c.get()) {
             gfir_instruction i = blank(GFIR_CONST);
-            i.imm[0] = static_cast<double> (c->evaluate().at(0));
+            const T value = c->evaluate().at(0);
+            i.imm[0] = real_part(value);
+            i.imm[1] = imaginary_part(value);
             slot = emit(i);
         } else if (auto v = graph::variable_cast(n); v.get()) {
             auto in = inputs.find(n.get());
@@ -163,8 +196,8 @@ private:
             i.a = lower(x->get_arg());
             const backend::buffer<T> data = x->evaluate();
             i.aux = add_table(data, 1, static_cast<uint32_t> (data.size()));
-            i.imm[0] = static_cast<double> (x->get_scale());
-            i.imm[1] = static_cast<double> (x->get_offset());
+            i.imm[0] = real_part(x->get_scale());
+            i.imm[1] = real_part(x->get_offset());
             slot = emit(i);
         } else if (auto x = graph::piecewise_2D_cast(n); x.get()) {
             gfir_instruction i = blank(GFIR_GATHER2);
@@ -172,10 +205,10 @@ private:
             const backend::buffer<T> data = x->evaluate();
             i.aux = add_table(data, static_cast<uint32_t> (x->get_num_rows()),
                               static_cast<uint32_t> (x->get_num_columns()));
-            i.imm[0] = static_cast<double> (x->get_x_scale());
-            i.imm[1] = static_cast<double> (x->get_x_offset());
-            i.imm[2] = static_cast<double> (x->get_y_scale());
-            i.imm[3] = static_cast<double> (x->get_y_offset());
+            i.imm[0] = real_part(x->get_x_scale());
+            i.imm[1] = real_part(x->get_x_offset());
+            i.imm[2] = real_part(x->get_y_scale());
+            i.imm[3] = real_part(x->get_y_offset());
             slot = emit(i);
         } else if (auto x = graph::index_1D_cast(n); x.get()) {
 //  v[idx(arg)]: the argument is compiled first, the variable is only named (piecewise.hpp:1530-1575).
@@ -183,8 +216,8 @@ private:
             i.a = lower(x->get_right());
             i.c = input_of(x->get_left());
             i.aux = static_cast<uint32_t> (x->get_size());
-            i.imm[0] = static_cast<double> (std::real(x->get_scale()));
-            i.imm[1] = static_cast<double> (std::real(x->get_offset()));
+            i.imm[0] = real_part(x->get_scale());
+            i.imm[1] = real_part(x->get_offset());
             slot = emit(i);
         } else if (auto x = graph::index_2D_cast(n); x.get()) {
             gfir_instruction i = blank(GFIR_INDEX2);
@@ -194,16 +227,38 @@ private:
             const size_t columns = columns_of_index_2D(n.get());
             i.aux = static_cast<uint32_t> (columns);
             i.reserved = static_cast<uint32_t> (x->get_size()/columns);
-            i.imm[0] = static_cast<double> (std::real(x->get_x_scale()));
-            i.imm[1] = static_cast<double> (std::real(x->get_x_offset()));
-            i.imm[2] = static_cast<double> (std::real(x->get_y_scale()));
-            i.imm[3] = static_cast<double> (std::real(x->get_y_offset()));
+            i.imm[0] = real_part(x->get_x_scale());
+            i.imm[1] = real_part(x->get_x_offset());
+            i.imm[2] = real_part(x->get_y_scale());
+            i.imm[3] = real_part(x->get_y_offset());
             slot = emit(i);
         } else {
-            throw std::runtime_error("gfir: unsupported node type (random, erfi or complex)");
+            throw std::runtime_error("gfir: unsupported node type (erfi)");
         }
         slots[n.get()] = slot;
         return slot;
+    }
+
+    uint32_t draw() {
+        if (last_draw == GFIR_NONE) {
+            last_draw = emit(blank(GFIR_CONST));                // the token the first draw hangs on
+        }
+        gfir_instruction i = blank(GFIR_RANDOM);
+        i.a = last_draw;
+        last_draw = emit(i);
+        return last_draw;
+    }
+
+//  What a store of `expression` reads.  Under SAFE_MATH the store is `isnan(e) ? 0 : e`
+//  (cpu_context.hpp:530-547) with e the node's register TEXT: for a random node that is two
+//  calls of random(state), and the value stored is the second draw.
+    uint32_t stored(graph::shared_leaf<T, SAFE_MATH> expression) {
+        if constexpr (SAFE_MATH) {
+            if (graph::random_cast(expression).get()) {
+                draw();
+            }
+        }
+        return lower(expression);
     }
 
     uint32_t input_of(graph::shared_leaf<T, SAFE_MATH> variable) {
@@ -266,9 +321,8 @@ public:
                                     graph::input_nodes<T, SAFE_MATH> in,
                                     graph::output_nodes<T, SAFE_MATH> out,
                                     graph::map_nodes<T, SAFE_MATH> setters) {
-        static_assert(std::is_same<T, float>::value || std::is_same<T, double>::value,
-                      "gfir: real base types only");
         code.clear(); slots.clear(); inputs.clear(); symbols.clear(); tables.clear();
+        last_draw = GFIR_NONE;
 
         for (size_t i = 0, ie = in.size(); i < ie; i++) {
             inputs[in[i].get()] = static_cast<uint32_t> (i);
@@ -278,20 +332,21 @@ public:
         std::vector<gfir_setter> set;
         for (auto &[expression, variable] : setters) {
             gfir_setter s;
-            s.value = lower(expression);
+            s.value = stored(expression);
             s.input = inputs.at(variable.get());
             set.push_back(s);
         }
         std::vector<uint32_t> outs;
         for (auto &o : out) {
-            outs.push_back(lower(o));
+            outs.push_back(stored(o));
         }
 
         std::vector<uint8_t> bytes;
         gfir_header h;
         std::memset(&h, 0, sizeof(h));
         std::memcpy(h.magic, GFIR_MAGIC, 8);
-        h.dtype = std::is_same<T, float>::value ? GFIR_F32 : GFIR_F64;
+        h.dtype = jit::complex_scalar<T> ? (jit::float_base<T> ? GFIR_C32 : GFIR_C64) : (jit::float_base<T> ? GFIR_F32 : GFIR_F64);
+        h.flags = SAFE_MATH ? GFIR_SAFE_MATH : 0;
         h.num_inputs = static_cast<uint32_t> (in.size());
         h.num_outputs = static_cast<uint32_t> (outs.size());
         h.num_setters = static_cast<uint32_t> (set.size());

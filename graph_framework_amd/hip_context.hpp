@@ -15,9 +15,10 @@
 ///  kernel.  The text stream is still fed (registers must exist for the nodes'
 ///  compile() methods to run) but is otherwise ignored.
 ///
-///  Real base types only: complex types and SAFE_MATH guards
-///  (cpu_context.hpp:530-547) and random state kernels are not on this path
-///  and abort with a message, like the reference's own unsupported cases.
+///  All eight flavours of the reference are served: float, double and their
+///  complex forms, with and without the SAFE_MATH guards (cpu_context.hpp:530-547,
+///  arithmetic.hpp:2534-2557), and kernels with a random state (random.hpp).  Only
+///  erfi nodes (special_functions.hpp) are not lowered.
 //------------------------------------------------------------------------------
 #ifndef hip_context_h
 #define hip_context_h
@@ -114,11 +115,6 @@ namespace gpu {
 ///  @param[in] index Concurrent index.
 //------------------------------------------------------------------------------
         hip_context(const size_t index) : remaining_const_memory(0) {
-            if constexpr (jit::complex_scalar<T> || SAFE_MATH) {
-                std::cerr << "hip_context: complex base types and SAFE_MATH are not served by the HIP backend."
-                          << std::endl;
-                exit(-1);
-            }
             context = gfhip_create_context(static_cast<int> (index), nullptr);
             if (!context) {
                 std::cerr << "hip_context: " << gfhip_last_error(nullptr) << std::endl;
@@ -128,6 +124,28 @@ namespace gpu {
 
         ~hip_context() {
             gfhip_destroy_context(context);
+        }
+
+//  The context owns device state: it moves (graph_set_device_number assigns a fresh
+//  workflow::manager over the old one, graph_c_binding.cpp:1939-1980) but does not copy.
+        hip_context(const hip_context &) = delete;
+        hip_context &operator=(const hip_context &) = delete;
+        hip_context(hip_context &&other) noexcept :
+        context(other.context), pending(std::move(other.pending)), kernels(std::move(other.kernels)),
+        reductions(std::move(other.reductions)), remaining_const_memory(other.remaining_const_memory) {
+            other.context = nullptr;
+        }
+        hip_context &operator=(hip_context &&other) noexcept {
+            if (this != &other) {
+                gfhip_destroy_context(context);
+                context = other.context;
+                other.context = nullptr;
+                pending = std::move(other.pending);
+                kernels = std::move(other.kernels);
+                reductions = std::move(other.reductions);
+                remaining_const_memory = other.remaining_const_memory;
+            }
+            return *this;
         }
 
 //------------------------------------------------------------------------------
@@ -156,14 +174,12 @@ namespace gpu {
                                   jit::texture1d_list &textures1d,
                                   jit::texture2d_list &textures2d) {
             (void)is_constant; (void)usage; (void)textures1d; (void)textures2d;
-            if (state.get()) {
-                std::cerr << "hip_context: kernels with a random state are not served by the HIP backend."
-                          << std::endl;
-                exit(-1);
-            }
             source_buffer << "// kernel " << name << std::endl;
             for (auto &input : inputs) {
                 registers[input.get()] = jit::to_string('v', input.get());
+            }
+            if (state.get()) {
+                registers[state.get()] = jit::to_string('s', state.get());      // random_node::compile reads it
             }
             pending_item item;
             item.name = name;
@@ -189,7 +205,7 @@ namespace gpu {
                                    const jit::register_usage &usage) {
             (void)outputs; (void)state; (void)registers; (void)indices; (void)usage;
             source_buffer << "// end kernel" << std::endl;
-            if constexpr (!jit::complex_scalar<T>) {
+            {
                 pending_item &item = pending.back();
 //  The stores the reference's postfix would emit (cpu_context.hpp:522-580): setters whose
 //  expression is not the variable itself, then outputs that are neither variables nor already
@@ -260,7 +276,7 @@ namespace gpu {
                                                      const size_t num_rays,
                                                      const jit::texture1d_list &tex1d_list,
                                                      const jit::texture2d_list &tex2d_list) {
-            (void)state; (void)inputs; (void)tex1d_list; (void)tex2d_list;
+            (void)inputs; (void)tex1d_list; (void)tex2d_list;
             auto found = kernels.find(kernel_name);
             if (found == kernels.end() || !found->second.kernel) {
                 std::cerr << "hip_context: kernel " << kernel_name << " was not added and compiled." << std::endl;
@@ -287,7 +303,12 @@ namespace gpu {
             check(gfhip_create_kernel_call(kernel, input_keys.data(), initial_pointers.data(), initial_counts.data(),
                                            output_keys.data()), "gfhip_create_kernel_call");
 //  Every listed node gets its buffer on first sight, stored by this kernel or not.
-            const uint32_t dtype = std::is_same<T, float>::value ? GFIR_F32 : GFIR_F64;
+            const uint32_t dtype = jit::complex_scalar<T> ? (jit::float_base<T> ? GFIR_C32 : GFIR_C64)
+                                                          : (jit::float_base<T> ? GFIR_F32 : GFIR_F64);
+            if (state.get()) {
+                check(gfhip_set_random_state(kernel, key(state.get()), state->data(), state->get_size_bytes()),
+                      "gfhip_set_random_state");
+            }
             for (auto &output : outputs) {
                 check(gfhip_allocate_buffer(context, key(output.get()), num_rays, dtype), "gfhip_allocate_buffer");
             }
@@ -313,9 +334,13 @@ namespace gpu {
             }
             gfhip_kernel *kernel = found->second;
             return [this, kernel] () mutable {
-                double value;
-                check(gfhip_run_max(kernel, &value), "gfhip_run_max");
-                return static_cast<T> (value);
+                double value[2];
+                check(gfhip_run_max_complex(kernel, value), "gfhip_run_max");
+                if constexpr (jit::complex_scalar<T>) {
+                    return T(static_cast<typename T::value_type> (value[0]), static_cast<typename T::value_type> (value[1]));
+                } else {
+                    return static_cast<T> (value[0]);
+                }
             };
         }
 
@@ -342,9 +367,9 @@ namespace gpu {
 //------------------------------------------------------------------------------
         T check_value(const size_t index,
                       const graph::shared_leaf<T, SAFE_MATH> &node) {
-            double value;
-            check(gfhip_check_value(context, key(node.get()), index, &value), "gfhip_check_value");
-            return static_cast<T> (value);
+            T value;
+            check(gfhip_read_element(context, key(node.get()), index, &value), "gfhip_read_element");
+            return value;
         }
 
 //------------------------------------------------------------------------------

@@ -91,6 +91,11 @@ int gfhip_run(gfhip_kernel *kernel, uint32_t steps);
  * create_max_call(arg, run)  (cuda_context.hpp:540-576, cpu_context.hpp:306-322). */
 int gfhip_run_max(gfhip_kernel *kernel, double *max_value);
 
+/* The same for items of a complex type (enum gfir_dtype GFIR_C32 / GFIR_C64): value[0] + i value[1] =
+ * the element of largest modulus of the last output, the first of equals, as
+ * cpu_context.hpp:314-318 selects it (std::max_element on std::abs). */
+int gfhip_run_max_complex(gfhip_kernel *kernel, double *value);
+
 /* The loop of workflow::converge_item::run (workflow.hpp:179-205) around
  * gfhip_run_max: repeat until |max| <= tol, or max stalls against the previous
  * or the previous-but-one value, or max_iterations.  The loop's test runs on the
@@ -129,8 +134,16 @@ int gfhip_copy_to_device(gfhip_context *ctx, uint64_t key, const void *host);
 int gfhip_copy_to_host(gfhip_context *ctx, uint64_t key, void *host);
 
 /* Read one element after draining the stream.  Replaces  T check_value(index, node)
- * (cuda_context.hpp:602-607). */
+ * (cuda_context.hpp:602-607).  gfhip_check_value returns it as a double (the real part of a
+ * complex element); gfhip_read_element copies the element itself (4, 8 or 16 bytes). */
 int gfhip_check_value(gfhip_context *ctx, uint64_t key, size_t index, double *value);
+int gfhip_read_element(gfhip_context *ctx, uint64_t key, size_t index, void *element);
+
+/* Bind the MT19937 states of the item's random_state node (random.hpp:24-130): `states` are
+ * the node's 1024 mt_state structures (state->data(), 2500 bytes each), uploaded on first
+ * sight of `key` and shared by every kernel bound to that key, as create_kernel_call does
+ * (cuda_context.hpp:367-380).  No-op for items without a random node. */
+int gfhip_set_random_state(gfhip_kernel *kernel, uint64_t key, const void *states, size_t bytes);
 
 /* Device pointer and element count of a buffer (NULL if the key is unknown).
  * The reference's get_buffer (cuda_context.hpp:650-652) returns the managed

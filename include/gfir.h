@@ -22,7 +22,8 @@
  *   char        name[name_bytes]                  (name_bytes % 4 == 0, NUL padded)
  *   per input:  uint32 bytes; char symbol[bytes]  (bytes % 4 == 0, NUL padded)
  *   per table:  gfir_table_header; double data[rows*cols]   (values exactly
- *               representable in the item's dtype)
+ *               representable in the item's dtype; complex items: (re, im) pairs,
+ *               2*rows*cols doubles)
  *   gfir_instruction ins[num_instructions]
  *   uint32      outputs[num_outputs]              (instruction index)
  *   gfir_setter setters[num_setters]
@@ -40,12 +41,19 @@ extern "C" {
 
 enum gfir_dtype {
     GFIR_F32 = 0,   /* graph_type FLOAT  (graph_c_binding.h:153-158) */
-    GFIR_F64 = 1    /* graph_type DOUBLE */
+    GFIR_F64 = 1,   /* graph_type DOUBLE */
+    GFIR_C32 = 2,   /* graph_type COMPLEX_FLOAT:  elements are (re, im) pairs of float  */
+    GFIR_C64 = 3    /* graph_type COMPLEX_DOUBLE: elements are (re, im) pairs of double */
 };
+
+/* gfir_header.flags */
+#define GFIR_SAFE_MATH 1u   /* the item was built with SAFE_MATH = true: guarded multiply, divide, fma and exp
+                               (arithmetic.hpp:2534-2557, :3526-3541, :5101-5117, math.hpp:450-471) and
+                               NaN -> 0 on every store (cpu_context.hpp:530-547) */
 
 /* One value per reference node class that can appear in a real-valued kernel. */
 enum gfir_op {
-    GFIR_CONST   = 0,   /* constant_node        node.hpp:729      imm[0] = value            */
+    GFIR_CONST   = 0,   /* constant_node        node.hpp:729      imm[0] = value (complex items: imm[0] + i imm[1]) */
     GFIR_INPUT   = 1,   /* variable_node        node.hpp:1386     a = input index           */
     GFIR_ADD     = 2,   /* add_node             arithmetic.hpp:132   a + b                  */
     GFIR_SUB     = 3,   /* subtract_node        arithmetic.hpp:879   a - b                  */
@@ -63,11 +71,15 @@ enum gfir_op {
     GFIR_GATHER1 = 15,  /* piecewise_1D_node    piecewise.hpp:105  table[idx(a; imm0 scale, imm1 offset)] */
     GFIR_GATHER2 = 16,  /* piecewise_2D_node    piecewise.hpp:686  table[idx(a; imm0, imm1)*cols + idx(b; imm2, imm3)] */
     GFIR_INDEX1  = 17,  /* index_1D_node        piecewise.hpp:1448 buffer of input c, [idx(a; imm0 scale, imm1 offset)], aux = its length */
-    GFIR_INDEX2  = 18   /* index_2D_node        piecewise.hpp:1788 buffer of input c, [idx(a; imm0, imm1)*aux + idx(b; imm2, imm3)],
+    GFIR_INDEX2  = 18,  /* index_2D_node        piecewise.hpp:1788 buffer of input c, [idx(a; imm0, imm1)*aux + idx(b; imm2, imm3)],
                            aux = columns, reserved = rows */
+    GFIR_RANDOM  = 19   /* random_node          random.hpp:296     one draw of the kernel's MT19937 state (random.hpp:318-339),
+                           converted to the item's type.  The reference prints this node as the TEXT `random(state)`
+                           wherever it is used (random.hpp:418), so every use is a draw of its own: one record per use,
+                           a = the previous draw (or a constant record for the first), which orders the draws. */
 };
 /* idx(x; scale, offset) = (uint)min(max((x - offset)/scale, 0), length - 1),
- * compile_index, piecewise.hpp:26-65. */
+ * compile_index, piecewise.hpp:26-65 (complex items: the real part of the quotient, :42-54). */
 
 struct gfir_header {
     char     magic[8];
@@ -78,7 +90,7 @@ struct gfir_header {
     uint32_t num_tables;
     uint32_t num_instructions;
     uint32_t name_bytes;
-    uint32_t reserved;
+    uint32_t flags;             /* GFIR_SAFE_MATH */
 };
 
 struct gfir_table_header {

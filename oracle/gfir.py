@@ -34,9 +34,14 @@ def lib():
         _lib.gfi_free.argtypes = [ctypes.c_void_p]
         _lib.gfi_info.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         _lib.gfi_setter_inputs.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        _lib.gfi_flags.restype = ctypes.c_uint32
+        _lib.gfi_flags.argtypes = [ctypes.c_void_p]
+        _lib.gfi_random_states.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32]
         for s in ("f64", "f32"):
             getattr(_lib, "gfi_run_" + s).argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                                       ctypes.c_size_t, ctypes.c_size_t]
+            getattr(_lib, "gfi_run_generic_" + s).argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                              ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p]
             f = getattr(_lib, "gfi_run_threads_" + s)
             f.restype = ctypes.c_double
             f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
@@ -58,8 +63,13 @@ class Item:
             raise ValueError("not a GFIR work item")
         info = (ctypes.c_uint32*6)()
         lib().gfi_info(self.handle, info)
-        self.dtype = "f64" if info[0] == 1 else "f32"
-        self.np_dtype = np.float64 if info[0] == 1 else np.float32
+        self.dtype = {0: "f32", 1: "f64", 2: "c32", 3: "c64"}[info[0]]
+        self.base = "f64" if info[0] in (1, 3) else "f32"
+        self.np_dtype = {0: np.float32, 1: np.float64, 2: np.complex64, 3: np.complex128}[info[0]]
+        flags = lib().gfi_flags(self.handle)
+        self.safe_math, self.has_random = bool(flags & 1), bool(flags & 0x100)
+        self.generic = info[0] >= 2 or self.safe_math or self.has_random
+        self.random_states = None
         self.num_inputs, self.num_outputs, self.num_setters = info[1], info[2], info[3]
         self.num_tables, self.num_instructions = info[4], info[5]
         si = (ctypes.c_uint32*max(self.num_setters, 1))()
@@ -83,11 +93,45 @@ class Item:
         """columns: list of num_inputs arrays (updated in place by setters).
         Returns (list of output arrays, wall seconds)."""
         assert len(columns) == self.num_inputs
+        if self.generic:
+            return self._run_generic(columns, steps)
         n = columns[0].size
         outs = [np.empty(n, dtype=self.np_dtype) for _ in range(self.num_outputs)]
         fn = getattr(lib(), "gfi_run_threads_" + self.dtype)
         secs = fn(self.handle, self._pointers(columns), self._pointers(outs), n, steps, threads)
         return outs, secs
+
+    STATE_BYTES = 2500                  # sizeof(mt_state): 624 words + a 16-bit index, 4-byte aligned (random.hpp:44-52)
+
+    def seed(self, seed=0):
+        """random_state_node(1024, seed): the states a kernel with draws works on (returned as the
+        bytes hip_context uploads; this item keeps and advances its own copy)."""
+        self.random_states = np.zeros(1024*self.STATE_BYTES, dtype=np.uint8)
+        lib().gfi_random_states(self.random_states.ctypes.data, 1024, int(seed))
+        return self.random_states.copy()
+
+    def _run_generic(self, columns, steps, size=None):
+        """Complex / SAFE_MATH / random items: serial loop, elements in order.  Inputs that index
+        nodes read may be longer than the ensemble; `size` (default: the shortest input, or the
+        first argument of run_sized) is the number of elements the kernel runs over."""
+        import time
+        n = size if size is not None else (min(c.size for c in columns) if columns else 1)
+        outs = [np.zeros(n, dtype=self.np_dtype) for _ in range(self.num_outputs)]
+        if self.has_random and self.random_states is None:
+            self.seed(0)
+        states = self.random_states.ctypes.data if self.random_states is not None else None
+        start = time.perf_counter()
+        fn = getattr(lib(), "gfi_run_generic_" + self.base)
+        for _ in range(steps):
+            fn(self.handle, self._pointers(columns), self._pointers(outs), 0, n, states)
+        return outs, time.perf_counter() - start
+
+    def run_sized(self, size, columns, steps=1):
+        """run() over `size` elements (items without inputs, or with indexed inputs of other lengths)."""
+        assert self.generic or all(c.size >= size for c in columns)
+        if self.generic:
+            return self._run_generic(columns, steps, size)
+        return self.run([c[:size] for c in columns], steps)
 
     def converge(self, columns, tolerance=1.0e-30, max_iterations=1000):
         """workflow::converge_item::run (workflow.hpp:179-205): repeat the kernel until the

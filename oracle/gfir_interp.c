@@ -75,7 +75,7 @@ gfi_item *gfi_load(const uint8_t *data, const size_t len) {
     for (uint32_t i = 0; i < h->num_tables; i++) {
         struct gfir_table_header th;
         TAKE(&th, sizeof(th));
-        const size_t count = (size_t)th.rows*th.cols;
+        const size_t count = (size_t)th.rows*th.cols*(h->dtype >= GFIR_C32 ? 2 : 1);
         item->table_rows[i] = th.rows;
         item->table_cols[i] = th.cols;
         item->tables_f64[i] = malloc(count*sizeof(double));
@@ -99,6 +99,15 @@ void gfi_info(const gfi_item *item, uint32_t *info6) {
     info6[3] = item->header.num_setters;
     info6[4] = item->header.num_tables;
     info6[5] = item->header.num_instructions;
+}
+
+/* header flags (GFIR_SAFE_MATH) | 0x100 if the item draws random numbers. */
+uint32_t gfi_flags(const gfi_item *item) {
+    uint32_t flags = item->header.flags;
+    for (uint32_t i = 0; i < item->header.num_instructions; i++) {
+        if (item->ins[i].op == GFIR_RANDOM) flags |= 0x100u;
+    }
+    return flags;
 }
 
 /* Which inputs a setter overwrites (info for callers). */
@@ -209,3 +218,193 @@ double gfi_run_threads_##SUFFIX(const gfi_item *item, REAL **columns, REAL **out
 
 DEFINE_RUN(f64, double, tables_f64, fma, sqrt, pow, sin, cos, atan2, exp, log, fmin, fmax)
 DEFINE_RUN(f32, float, tables_f32, fmaf, sqrtf, powf, sinf, cosf, atan2f, expf, logf, fminf, fmaxf)
+
+
+/* ---------------------------------------------------------------------------
+ * Items off the hot path: complex base types (GFIR_C32/GFIR_C64), SAFE_MATH guards, random draws.
+ * One value = (re, im) in the item's base precision; real items keep im = 0 and use the real
+ * formulas.  Complex arithmetic as graph_framework_amd/csrc/prelude.hpp states it (textbook
+ * product, Smith's quotient, every operation unfused): no fixture of the reference pins complex
+ * kernels, so this is the restatement both sides are held to ("parity unpinned").
+ * SAFE_MATH: arithmetic.hpp:2534-2557, :3526-3541, :5101-5117, math.hpp:450-471,
+ * cpu_context.hpp:530-547.  Random: random.hpp:318-339, one MT19937 state per lane of 1024
+ * (cuda_context.hpp:509-522, :817): element e draws from state e % 1024, elements in order.
+ * ------------------------------------------------------------------------- */
+typedef struct { uint32_t array[624]; uint16_t index; } gfi_mt_state;
+
+static uint32_t gfi_random(gfi_mt_state *state) {
+    const uint16_t k = state->index;
+    uint16_t j = (uint16_t)((k + 1)%624);
+    uint32_t x = (state->array[k] & 0x80000000u) | (state->array[j] & 0x7fffffffu);
+    uint32_t xa = x >> 1;
+    if (x & 1u) xa ^= 0x9908b0dfu;
+    j = (uint16_t)((k + 397)%624);
+    x = state->array[j]^xa;
+    state->array[k] = x;
+    state->index = (uint16_t)((k + 1)%624);
+    uint32_t y = x^(x >> 11);
+    y = y^((y << 7) & 0x9d2c5680u);
+    y = y^((y << 15) & 0xefc60000u);
+    return y^(y >> 18);
+}
+
+/* random_state_node::initialize_state, random.hpp:104-113: `count` states seeded seed, seed + 1, ... */
+void gfi_random_states(gfi_mt_state *states, const size_t count, const uint32_t seed) {
+    for (size_t s = 0; s < count; s++) {
+        states[s].array[0] = seed + (uint32_t)s;
+        for (uint32_t i = 1; i < 624; i++) {
+            states[s].array[i] = 1812433253u*(states[s].array[i - 1]^(states[s].array[i - 1] >> 30)) + i;
+        }
+        states[s].index = 0;
+    }
+}
+
+#define DEFINE_GENERIC(SUFFIX, REAL, TABLES, FMA, SQRT, POW, SIN, COS, ATAN2, EXP, LOG, FMIN, FMAX, FABS, HYPOT, SINH, COSH, BIG) \
+typedef struct { REAL re, im; } gfi_value_##SUFFIX;                                                      \
+static inline gfi_value_##SUFFIX gfi_mul_##SUFFIX(const gfi_value_##SUFFIX a, const gfi_value_##SUFFIX b, const int cx) { \
+    gfi_value_##SUFFIX v = {a.re*b.re, 0};                                                               \
+    if (cx) { v.re = a.re*b.re - a.im*b.im; v.im = a.re*b.im + a.im*b.re; }                              \
+    return v;                                                                                            \
+}                                                                                                        \
+static inline gfi_value_##SUFFIX gfi_div_##SUFFIX(const gfi_value_##SUFFIX a, const gfi_value_##SUFFIX b, const int cx) { \
+    gfi_value_##SUFFIX v = {0, 0};                                                                       \
+    if (!cx) { v.re = a.re/b.re; return v; }                                                             \
+    if (FABS(b.re) < FABS(b.im)) {                                                                       \
+        const REAL ratio = b.re/b.im, denom = b.re*ratio + b.im;                                         \
+        v.re = (a.re*ratio + a.im)/denom; v.im = (a.im*ratio - a.re)/denom;                              \
+    } else {                                                                                             \
+        const REAL ratio = b.im/b.re, denom = b.im*ratio + b.re;                                         \
+        v.re = (a.im*ratio + a.re)/denom; v.im = (a.im - a.re*ratio)/denom;                              \
+    }                                                                                                    \
+    return v;                                                                                            \
+}                                                                                                        \
+static inline gfi_value_##SUFFIX gfi_cexp_##SUFFIX(const gfi_value_##SUFFIX a) {                         \
+    const REAL e = EXP(a.re);                                                                            \
+    gfi_value_##SUFFIX v = {e*COS(a.im), e*SIN(a.im)};                                                   \
+    return v;                                                                                            \
+}                                                                                                        \
+static inline gfi_value_##SUFFIX gfi_clog_##SUFFIX(const gfi_value_##SUFFIX a) {                         \
+    gfi_value_##SUFFIX v = {LOG(HYPOT(a.re, a.im)), ATAN2(a.im, a.re)};                                  \
+    return v;                                                                                            \
+}                                                                                                        \
+static inline size_t gfi_gindex_##SUFFIX(const gfi_value_##SUFFIX x, const REAL scale, const REAL offset, \
+                                         const uint32_t length, const int cx) {                          \
+    const gfi_value_##SUFFIX numerator = {x.re - offset, x.im}, denominator = {scale, 0};                \
+    const REAL q = gfi_div_##SUFFIX(numerator, denominator, cx).re;                                      \
+    return (size_t)FMIN(FMAX(q, (REAL)0), (REAL)(length - 1));                                           \
+}                                                                                                        \
+/* Elements [begin, end); columns/outs hold (re, im) pairs for complex items, plain values otherwise. */ \
+void gfi_run_generic_##SUFFIX(const gfi_item *item, REAL **columns, REAL **outs, const size_t begin,    \
+                              const size_t end, gfi_mt_state *states) {                                  \
+    const uint32_t n_ins = item->header.num_instructions;                                                \
+    const int cx = item->header.dtype >= GFIR_C32;                                                       \
+    const int safe = (item->header.flags & GFIR_SAFE_MATH) != 0;                                         \
+    const size_t parts = cx ? 2 : 1;                                                                     \
+    gfi_value_##SUFFIX *r = malloc(sizeof(gfi_value_##SUFFIX)*(n_ins + 1));                              \
+    const gfi_value_##SUFFIX zero = {0, 0};                                                              \
+    for (size_t e = begin; e < end; e++) {                                                               \
+        for (uint32_t i = 0; i < n_ins; i++) {                                                           \
+            const struct gfir_instruction *c = &item->ins[i];                                            \
+            const gfi_value_##SUFFIX a = c->a < n_ins ? r[c->a] : zero, b = c->b < n_ins ? r[c->b] : zero, \
+                                     m = c->c < n_ins ? r[c->c] : zero;                                  \
+            gfi_value_##SUFFIX v = zero;                                                                 \
+            switch (c->op) {                                                                             \
+                case GFIR_CONST: v.re = (REAL)c->imm[0]; v.im = cx ? (REAL)c->imm[1] : 0; break;         \
+                case GFIR_INPUT: v.re = columns[c->a][e*parts]; v.im = cx ? columns[c->a][e*parts + 1] : 0; break; \
+                case GFIR_ADD: v.re = a.re + b.re; v.im = a.im + b.im; break;                            \
+                case GFIR_SUB: v.re = a.re - b.re; v.im = a.im - b.im; break;                            \
+                case GFIR_MUL:                                                                           \
+                    if (safe && ((a.re == 0 && a.im == 0) || (b.re == 0 && b.im == 0))) break;           \
+                    v = gfi_mul_##SUFFIX(a, b, cx); break;                                               \
+                case GFIR_DIV:                                                                           \
+                    if (safe && a.re == 0 && a.im == 0) break;                                           \
+                    v = gfi_div_##SUFFIX(a, b, cx); break;                                               \
+                case GFIR_FMA:                                                                           \
+                    if (safe && ((a.re == 0 && a.im == 0) || (b.re == 0 && b.im == 0))) { v = m; break; } \
+                    if (cx) { v = gfi_mul_##SUFFIX(a, b, 1); v.re += m.re; v.im += m.im; }               \
+                    else v.re = FMA(a.re, b.re, m.re);                                                   \
+                    break;                                                                               \
+                case GFIR_SQRT:                                                                          \
+                    if (!cx) { v.re = SQRT(a.re); break; }                                               \
+                    if (a.re == 0 && a.im == 0) { v.im = a.im; break; }                                  \
+                    {   const REAL mod = HYPOT(a.re, a.im);                                              \
+                        if (a.re >= 0) { const REAL t = SQRT((mod + a.re)*(REAL)0.5); v.re = t; v.im = a.im/(t + t); } \
+                        else { const REAL t = SQRT((mod - a.re)*(REAL)0.5); v.re = FABS(a.im)/(t + t); v.im = a.im < 0 ? -t : t; } \
+                    }                                                                                    \
+                    break;                                                                               \
+                case GFIR_POWI:                                                                          \
+                    v = a;                                                                               \
+                    for (uint32_t k = 1; k < c->aux; k++) v = gfi_mul_##SUFFIX(v, a, cx);                \
+                    break;                                                                               \
+                case GFIR_POW:                                                                           \
+                    if (!cx) { v.re = POW(a.re, b.re); break; }                                          \
+                    if (a.re == 0 && a.im == 0) { v.re = (b.re == 0 && b.im == 0) ? 1 : 0; break; }      \
+                    v = gfi_cexp_##SUFFIX(gfi_mul_##SUFFIX(b, gfi_clog_##SUFFIX(a), 1));                 \
+                    break;                                                                               \
+                case GFIR_SIN:                                                                           \
+                    if (cx) { v.re = SIN(a.re)*COSH(a.im); v.im = COS(a.re)*SINH(a.im); } else v.re = SIN(a.re); \
+                    break;                                                                               \
+                case GFIR_COS:                                                                           \
+                    if (cx) { v.re = COS(a.re)*COSH(a.im); v.im = -SIN(a.re)*SINH(a.im); } else v.re = COS(a.re); \
+                    break;                                                                               \
+                case GFIR_ATAN2:                                                                         \
+                    if (!cx) { v.re = ATAN2(b.re, a.re); break; }                                        \
+                    {   const gfi_value_##SUFFIX z = gfi_div_##SUFFIX(b, a, 1);                          \
+                        const gfi_value_##SUFFIX up = {z.re, (REAL)1 + z.im}, down = {-z.re, (REAL)1 - z.im}; \
+                        const gfi_value_##SUFFIX w = gfi_clog_##SUFFIX(gfi_div_##SUFFIX(up, down, 1));   \
+                        v.re = -w.im*(REAL)0.5; v.im = w.re*(REAL)0.5;                                   \
+                    }                                                                                    \
+                    break;                                                                               \
+                case GFIR_EXP:                                                                           \
+                    if (safe && !(a.re < (REAL)709.8)) { v.re = BIG; break; }                            \
+                    if (cx) v = gfi_cexp_##SUFFIX(a); else v.re = EXP(a.re);                             \
+                    break;                                                                               \
+                case GFIR_LOG:                                                                           \
+                    if (cx) v = gfi_clog_##SUFFIX(a); else v.re = LOG(a.re);                             \
+                    break;                                                                               \
+                case GFIR_GATHER1: {                                                                     \
+                    const size_t at = gfi_gindex_##SUFFIX(a, (REAL)c->imm[0], (REAL)c->imm[1], item->table_cols[c->aux], cx); \
+                    v.re = item->TABLES[c->aux][at*parts]; v.im = cx ? item->TABLES[c->aux][at*parts + 1] : 0; \
+                    break;                                                                               \
+                }                                                                                        \
+                case GFIR_GATHER2: {                                                                     \
+                    const size_t at = gfi_gindex_##SUFFIX(a, (REAL)c->imm[0], (REAL)c->imm[1], item->table_rows[c->aux], cx) \
+                                      *item->table_cols[c->aux] +                                        \
+                                      gfi_gindex_##SUFFIX(b, (REAL)c->imm[2], (REAL)c->imm[3], item->table_cols[c->aux], cx); \
+                    v.re = item->TABLES[c->aux][at*parts]; v.im = cx ? item->TABLES[c->aux][at*parts + 1] : 0; \
+                    break;                                                                               \
+                }                                                                                        \
+                case GFIR_INDEX1: {                                                                      \
+                    const size_t at = gfi_gindex_##SUFFIX(a, (REAL)c->imm[0], (REAL)c->imm[1], c->aux, cx); \
+                    v.re = columns[c->c][at*parts]; v.im = cx ? columns[c->c][at*parts + 1] : 0;         \
+                    break;                                                                               \
+                }                                                                                        \
+                case GFIR_INDEX2: {                                                                      \
+                    const size_t at = gfi_gindex_##SUFFIX(a, (REAL)c->imm[0], (REAL)c->imm[1], c->reserved, cx)*c->aux + \
+                                      gfi_gindex_##SUFFIX(b, (REAL)c->imm[2], (REAL)c->imm[3], c->aux, cx); \
+                    v.re = columns[c->c][at*parts]; v.im = cx ? columns[c->c][at*parts + 1] : 0;         \
+                    break;                                                                               \
+                }                                                                                        \
+                case GFIR_RANDOM: v.re = (REAL)gfi_random(&states[e%1024]); break;                       \
+                default: v.re = (REAL)NAN;                                                               \
+            }                                                                                            \
+            r[i] = v;                                                                                    \
+        }                                                                                                \
+        for (uint32_t s = 0; s < item->header.num_setters; s++) {                                        \
+            gfi_value_##SUFFIX v = r[item->setters[s].value];                                            \
+            if (safe) { if (v.re != v.re) v.re = 0; if (v.im != v.im) v.im = 0; }                        \
+            columns[item->setters[s].input][e*parts] = v.re;                                             \
+            if (cx) columns[item->setters[s].input][e*parts + 1] = v.im;                                 \
+        }                                                                                                \
+        for (uint32_t o = 0; o < item->header.num_outputs; o++) {                                        \
+            gfi_value_##SUFFIX v = r[item->outputs[o]];                                                  \
+            if (safe) { if (v.re != v.re) v.re = 0; if (v.im != v.im) v.im = 0; }                        \
+            outs[o][e*parts] = v.re;                                                                     \
+            if (cx) outs[o][e*parts + 1] = v.im;                                                         \
+        }                                                                                                \
+    }                                                                                                    \
+    free(r);                                                                                             \
+}
+
+DEFINE_GENERIC(f64, double, tables_f64, fma, sqrt, pow, sin, cos, atan2, exp, log, fmin, fmax, fabs, hypot, sinh, cosh, 1.7976931348623157e308)
+DEFINE_GENERIC(f32, float, tables_f32, fmaf, sqrtf, powf, sinf, cosf, atan2f, expf, logf, fminf, fmaxf, fabsf, hypotf, sinhf, coshf, 3.4028234663852886e38f)
