@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _lib
 
-_NP = {_lib.GFIR_F32: np.float32, _lib.GFIR_F64: np.float64}
+_NP = {_lib.GFIR_F32: np.float32, _lib.GFIR_F64: np.float64, _lib.GFIR_C32: np.complex64, _lib.GFIR_C64: np.complex128}
 
 
 def key_of(name):
@@ -121,8 +121,10 @@ class Context:
         if not pointer:
             raise GfHipError(self.lib.gfhip_last_error(self.handle).decode())
         _, dtype = self.buffer_info(key)
-        ctype = ctypes.c_double if dtype is np.float64 else ctypes.c_float
-        return np.ctypeslib.as_array(ctypes.cast(pointer, ctypes.POINTER(ctype)), shape=(count.value,))
+        base = ctypes.c_double if dtype in (np.float64, np.complex128) else ctypes.c_float
+        parts = 2 if dtype in (np.complex64, np.complex128) else 1
+        flat = np.ctypeslib.as_array(ctypes.cast(pointer, ctypes.POINTER(base)), shape=(count.value*parts,))
+        return flat.view(dtype) if parts == 2 else flat
 
     def check_value(self, index, key):
         value = ctypes.c_double()
@@ -186,6 +188,17 @@ class Kernel:
                 init[i] = value.ctypes.data
                 counts[i] = self.num_rays
         self.context._check(self.lib.gfhip_create_kernel_call(self.handle, in_keys, init, counts, out_keys))
+
+    def set_random_state(self, key, states):
+        """Bind the MT19937 states of the item's random_state node (random.hpp:24-130): the bytes of
+        1024 mt_state structures, uploaded on first sight of `key`."""
+        states = np.ascontiguousarray(states, dtype=np.uint8)
+        self.context._check(self.lib.gfhip_set_random_state(self.handle, key_of(key), states.ctypes.data, states.size))
+
+    def run_max_complex(self):
+        value = (ctypes.c_double*2)()
+        self.context._check(self.lib.gfhip_run_max_complex(self.handle, value))
+        return complex(value[0], value[1])
 
     def run(self, steps=1):
         self.context._check(self.lib.gfhip_run(self.handle, int(steps)))

@@ -372,6 +372,9 @@ struct kernel_writer {
         for (size_t p = 0; p < out.packs.size(); p++) {
             s << "const real *__restrict__ " << (out.packs[p].in_lds ? "lds" : "pack") << p << ", ";
         }
+        for (size_t i = 0; i < it.symbols.size(); i++) {               // buffers that index nodes read
+            if (it.indexed_length(static_cast<uint32_t> (i))) s << "const real *in" << i << ", ";
+        }
         if (park_slots) s << "park_t *park, park_t *park_read, ";
         s << "const int) {\n";
         s << "            " << results << " redo;\n";
@@ -545,6 +548,9 @@ struct kernel_writer {
               << "                const " << out.kernel_name << "_results redo = " << out.kernel_name << "_ieee(";
             for (size_t i = 0; i < it.symbols.size(); i++) s << "v" << i << ", ";
             for (size_t p = 0; p < out.packs.size(); p++) s << (out.packs[p].in_lds ? "lds" : "pack") << p << ", ";
+            for (size_t i = 0; i < it.symbols.size(); i++) {
+                if (it.indexed_length(static_cast<uint32_t> (i))) s << "in" << i << ", ";
+            }
             if (park_slots) s << "park, park_read, ";
             s << "0);\n";
             for (size_t k = 0; k < it.setters.size(); k++) s << "                sv" << k << " = redo.sv" << k << ";\n";
