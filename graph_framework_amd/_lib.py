@@ -61,6 +61,7 @@ SYMBOLS = [
     ("gfhip_kernel_get_info", _I, [_P, ctypes.POINTER(KernelInfo)]),
     ("gfhip_generate_source", _P, [_P, _S, ctypes.POINTER(_U64)]),
     ("gfhip_free_string", None, [_P]),
+    ("gfhip_cli_distribution", None, [_U64, _S, _P, _P, _P]),
     ("gfhip_enable_timing", _I, [_P, _I]),
     ("gfhip_kernel_timing", _I, [_P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_U64)]),
     ("gfhip_kernel_timing_samples", _I, [_P, ctypes.POINTER(ctypes.c_double), _S, ctypes.POINTER(_S)]),

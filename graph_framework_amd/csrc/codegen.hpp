@@ -297,6 +297,9 @@ struct kernel_writer {
                 case GFIR_LOG:
                     s << ind << "const real r" << i << " = " << call("log", "gf_log") << "(" << N(c.a) << ");\n";
                     break;
+                case GFIR_ERFI:
+                    s << ind << "const real r" << i << " = gf_erfi(" << N(c.a) << ");\n";
+                    break;
                 case GFIR_GATHER1:
                 case GFIR_GATHER2: {
                     const table &t = it.tables[c.aux];

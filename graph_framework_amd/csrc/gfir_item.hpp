@@ -170,6 +170,7 @@ struct item {
                 case GFIR_FMA: ok = before(c.a) && before(c.b) && before(c.c); break;
                 case GFIR_SQRT: case GFIR_SIN: case GFIR_COS: case GFIR_EXP: case GFIR_LOG:
                     ok = before(c.a); break;
+                case GFIR_ERFI: ok = before(c.a) && (h.dtype == GFIR_C32 || h.dtype == GFIR_C64); break;
                 case GFIR_POWI: ok = before(c.a) && c.aux >= 1 && c.aux <= 64; break;
                 case GFIR_GATHER1:
                     ok = before(c.a) && c.aux < h.num_tables && tables[c.aux].rows == 1; break;

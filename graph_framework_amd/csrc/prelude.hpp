@@ -32,8 +32,11 @@
 #ifndef gfhip_prelude_hpp
 #define gfhip_prelude_hpp
 
+#include <cmath>
+#include <cstdio>
 #include <sstream>
 #include <string>
+#include <vector>
 
 #include "gfir_item.hpp"
 #include "options.hpp"
@@ -122,6 +125,86 @@ __device__ __forceinline__ gf_complex gf_from_base(const base a) { return gf_com
 )";
 }
 
+//  erfi for complex arguments (erfi_node, math.hpp:1440; the reference calls special::erfi,
+//  special_functions.hpp:1583, a port of the Faddeeva package).  Here: erfi(z) = -i erf(iz) with
+//  erf(u) = 1 - exp(-u^2) w(iu) and the Faddeeva function w by Weideman's rational approximation
+//  (J. A. C. Weideman, SIAM J. Numer. Anal. 31 (1994) 1497: w(z) ~ 2 p(Z)/(L - iz)^2 +
+//  (1/sqrt(pi))/(L - iz), Z = (L + iz)/(L - iz), p of degree N - 1 with Fourier coefficients of
+//  exp(-t^2)(L^2 + t^2), L = sqrt(N/sqrt 2); lower half plane: w(z) = 2 exp(-z^2) - w(-z)).
+//  N = 48 meets the reference's own test of its erfi (graph_tests/erfi_test.cpp:20-83 on
+//  graph_tests/test_erfi.nc: |1 - test/gold| <= 2e-14): tests/test_oracle.py, tests/test_gpu_generic.py.
+//  Evaluated in double whatever the item's base type.
+inline void weideman_coefficients(const int n, double &length, std::vector<double> &a) {
+    const int m = 2*n, m2 = 2*m;
+    const long double pi = 3.141592653589793238462643383279502884L;
+    const long double l = std::sqrt(static_cast<long double> (n)/std::sqrt(2.0L));
+    length = static_cast<double> (l);
+    std::vector<long double> f(m2, 0.0L);                   // f[0] = 0, f[j] for k = j - m, j = 1 .. 4n - 1
+    for (int j = 1; j < m2; j++) {
+        const long double t = l*std::tan((j - m)*pi/m/2.0L);
+        f[j] = std::exp(-t*t)*(l*l + t*t);
+    }
+    a.assign(n, 0.0);
+    for (int k = 1; k <= n; k++) {                          // real part of the DFT of fftshift(f), / 4n
+        long double sum = 0.0L;
+        for (int j = 0; j < m2; j++) {
+            sum += f[(j + m2/2)%m2]*std::cos(2.0L*pi*k*j/m2);
+        }
+        a[k - 1] = static_cast<double> (sum/m2);            // coefficient of Z^(k - 1)
+    }
+}
+
+inline void emit_erfi(std::ostringstream &s) {
+    double length;
+    std::vector<double> a;
+    weideman_coefficients(48, length, a);
+    char buf[64];
+    s << "__device__ static const double gf_weideman[48] = {";
+    for (size_t k = 0; k < a.size(); k++) {
+        std::snprintf(buf, sizeof(buf), "%a", a[k]);
+        s << (k ? ", " : "") << buf;
+    }
+    std::snprintf(buf, sizeof(buf), "%a", length);
+    s << "};\n#define GF_WEIDEMAN_L " << buf << "\n";
+    s << R"(
+struct gf_z { double re, im; };
+__device__ __forceinline__ gf_z gf_zmul(const gf_z a, const gf_z b) { return gf_z{a.re*b.re - a.im*b.im, a.re*b.im + a.im*b.re}; }
+__device__ __forceinline__ gf_z gf_zdiv(const gf_z a, const gf_z b) {
+    const double d = b.re*b.re + b.im*b.im;
+    return gf_z{(a.re*b.re + a.im*b.im)/d, (a.im*b.re - a.re*b.im)/d};
+}
+__device__ __forceinline__ gf_z gf_zexp(const gf_z a) { const double e = exp(a.re); return gf_z{e*cos(a.im), e*sin(a.im)}; }
+// w(z) for Im z >= 0
+__device__ inline gf_z gf_faddeeva_upper(const gf_z z) {
+    const gf_z down{GF_WEIDEMAN_L + z.im, -z.re};           // L - iz
+    const gf_z up{GF_WEIDEMAN_L - z.im, z.re};              // L + iz
+    const gf_z big = gf_zdiv(up, down);
+    gf_z p{gf_weideman[47], 0.0};
+    for (int k = 46; k >= 0; k--) {
+        p = gf_zmul(p, big);
+        p.re += gf_weideman[k];
+    }
+    const gf_z first = gf_zdiv(gf_z{2.0*p.re, 2.0*p.im}, gf_zmul(down, down));
+    const gf_z second = gf_zdiv(gf_z{0x1.20dd750429b6dp-1, 0.0}, down);       // 1/sqrt(pi)
+    return gf_z{first.re + second.re, first.im + second.im};
+}
+__device__ inline gf_z gf_faddeeva(const gf_z z) {
+    if (z.im >= 0.0) return gf_faddeeva_upper(z);
+    const gf_z square = gf_zmul(z, z);
+    const gf_z e = gf_zexp(gf_z{-square.re, -square.im});
+    const gf_z w = gf_faddeeva_upper(gf_z{-z.re, -z.im});
+    return gf_z{2.0*e.re - w.re, 2.0*e.im - w.im};
+}
+__device__ inline gf_complex gf_erfi(const gf_complex a) {
+    const gf_z z{static_cast<double> (a.re), static_cast<double> (a.im)};
+    const gf_z e = gf_zexp(gf_zmul(z, z));                                       // exp(-u^2), u = iz
+    const gf_z w = gf_faddeeva(gf_z{-z.re, -z.im});                              // w(iu) = w(-z)
+    const gf_z erf{1.0 - (e.re*w.re - e.im*w.im), -(e.re*w.im + e.im*w.re)};    // erf(iz)
+    return gf_complex(static_cast<base> (erf.im), static_cast<base> (-erf.re)); // -i erf(iz)
+}
+)";
+}
+
 //  What items with complex values, SAFE_MATH guards or a random state call by name (the plain
 //  real-valued hot path keeps the builtins in its text).
 inline void emit_generic(std::ostringstream &s, const item &it, const bool f64) {
@@ -174,6 +257,12 @@ inline void emit_prelude(std::ostringstream &s, const item &it, const codegen_op
     s << "typedef " << base << " base;\n";
     if (it.is_complex()) {
         emit_complex(s, f64);
+        for (auto &c : it.code) {
+            if (c.op == GFIR_ERFI) {
+                emit_erfi(s);
+                break;
+            }
+        }
         s << "typedef gf_complex real;\n";
     } else {
         s << "typedef base real;\n";

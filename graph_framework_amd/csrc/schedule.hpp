@@ -29,7 +29,7 @@ inline int operand_count(const uint32_t op) {
     switch (op) {
         case GFIR_CONST: case GFIR_INPUT: return 0;
         case GFIR_FMA: return 3;
-        case GFIR_SQRT: case GFIR_POWI: case GFIR_SIN: case GFIR_COS: case GFIR_EXP: case GFIR_LOG:
+        case GFIR_SQRT: case GFIR_POWI: case GFIR_SIN: case GFIR_COS: case GFIR_EXP: case GFIR_LOG: case GFIR_ERFI:
         case GFIR_GATHER1: case GFIR_INDEX1: case GFIR_RANDOM: return 1;
         default: return 2;
     }

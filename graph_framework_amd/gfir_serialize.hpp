@@ -210,6 +210,10 @@ private:
             i.imm[2] = real_part(x->get_y_scale());
             i.imm[3] = real_part(x->get_y_offset());
             slot = emit(i);
+        } else if (auto x = graph::erfi_cast(n); x.get()) {
+            gfir_instruction i = blank(GFIR_ERFI);
+            i.a = lower(x->get_arg());
+            slot = emit(i);
         } else if (auto x = graph::index_1D_cast(n); x.get()) {
 //  v[idx(arg)]: the argument is compiled first, the variable is only named (piecewise.hpp:1530-1575).
             gfir_instruction i = blank(GFIR_INDEX1);
@@ -233,7 +237,7 @@ private:
             i.imm[3] = real_part(x->get_y_offset());
             slot = emit(i);
         } else {
-            throw std::runtime_error("gfir: unsupported node type (erfi)");
+            throw std::runtime_error("gfir: unsupported node type");
         }
         slots[n.get()] = slot;
         return slot;

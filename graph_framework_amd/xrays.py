@@ -39,19 +39,18 @@ def cli_distribution(num_rays, seed=0, dtype="f64"):
     """The incoherent initial conditions of the xrays CLI example (graph_driver/xrays.cpp:392-399,
     :448-453; graph_driver/CMakeLists.txt:5-31): cylindrical r = 2.5, phi ~ N(0, 0.05),
     z ~ N(0, 0.05), ky ~ N(-100, 10), kz ~ N(0, 10), omega ~ N(700, 10), kx guess -700 (then
-    Newton), seed = shard index.  The reference draws with std::mt19937_64 +
-    std::normal_distribution (libstdc++-specific); this generator keeps the distributions and
-    the per-shard seeding but draws with numpy's PCG64, so the samples differ."""
-    rng = np.random.default_rng(seed)
+    Newton), seed = shard index — the reference's own samples: std::mt19937_64 and libstdc++'s
+    std::normal_distribution restated in csrc/cli_distribution.cpp (pinned to samples of the real
+    objects, tests/golden/cli_distribution_golden.npz)."""
+    import ctypes
+    lib = _lib.load()
+    means = (ctypes.c_double*7)(700.0, -700.0, -100.0, 0.0, 0.0, 2.5, 0.0)           # omega, kx, ky, kz, z, radius, phi
+    sigmas = (ctypes.c_double*7)(10.0, 0.0, 10.0, 10.0, 0.05, 0.0, 0.05)
+    columns = [np.empty(num_rays, dtype=np.float64) for _ in STATE]
+    pointers = (ctypes.c_void_p*8)(*[c.ctypes.data for c in columns])
+    lib.gfhip_cli_distribution(int(seed), int(num_rays), means, sigmas, pointers)
     np_dtype = _NP[dtype]
-    w = rng.normal(700.0, 10.0, num_rays)
-    kx = np.full(num_rays, -700.0)
-    ky = rng.normal(-100.0, 10.0, num_rays)
-    kz = rng.normal(0.0, 10.0, num_rays)
-    z = rng.normal(0.0, 0.05, num_rays)
-    phi = rng.normal(0.0, 0.05, num_rays)
-    state = dict(t=np.zeros(num_rays), w=w, x=2.5*np.cos(phi), y=2.5*np.sin(phi), z=z, kx=kx, ky=ky, kz=kz)
-    return {k: np.ascontiguousarray(v, dtype=np_dtype) for k, v in state.items()}
+    return {k: np.ascontiguousarray(c, dtype=np_dtype) for k, c in zip(STATE, columns)}
 
 
 class RaySolver:

@@ -190,6 +190,13 @@ int gfhip_kernel_get_info(const gfhip_kernel *kernel, struct gfhip_kernel_info *
 char *gfhip_generate_source(const void *gfir, size_t bytes, uint64_t *source_hash);
 void gfhip_free_string(char *text);
 
+/* Host side, no device: the initial conditions of the xrays command line for one shard, sample
+ * for sample (graph_driver/xrays.cpp:397-453: std::mt19937_64(seed = shard index), libstdc++'s
+ * std::normal_distribution per variable, drawn in the order omega, kx, ky, kz, z, (x, y)).
+ * means/sigmas: 7 doubles each in that order with (radius, phi) last, sigma <= 0 = the mean, no
+ * draw; columns: 8 arrays of n doubles, t, w, x, y, z, kx, ky, kz. */
+void gfhip_cli_distribution(uint64_t seed, size_t n, const double *means, const double *sigmas, double *const *columns);
+
 /* Average duration in milliseconds of the launches of `kernel` recorded since
  * the last call: HIP events on the context's stream around every `enable`-th
  * launch of each kernel (1 = every launch, 0 = off; a pair of event records

@@ -73,6 +73,7 @@ enum gfir_op {
     GFIR_INDEX1  = 17,  /* index_1D_node        piecewise.hpp:1448 buffer of input c, [idx(a; imm0 scale, imm1 offset)], aux = its length */
     GFIR_INDEX2  = 18,  /* index_2D_node        piecewise.hpp:1788 buffer of input c, [idx(a; imm0, imm1)*aux + idx(b; imm2, imm3)],
                            aux = columns, reserved = rows */
+    GFIR_ERFI    = 20,  /* erfi_node            math.hpp:1440      erfi(a), complex items (special::erfi, special_functions.hpp:1583) */
     GFIR_RANDOM  = 19   /* random_node          random.hpp:296     one draw of the kernel's MT19937 state (random.hpp:318-339),
                            converted to the item's type.  The reference prints this node as the TEXT `random(state)`
                            wherever it is used (random.hpp:418), so every use is a draw of its own: one record per use,

@@ -37,6 +37,7 @@ def lib():
         _lib.gfi_flags.restype = ctypes.c_uint32
         _lib.gfi_flags.argtypes = [ctypes.c_void_p]
         _lib.gfi_random_states.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32]
+        _lib.gfi_erfi.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_void_p]
         for s in ("f64", "f32"):
             getattr(_lib, "gfi_run_" + s).argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                                       ctypes.c_size_t, ctypes.c_size_t]
@@ -47,6 +48,13 @@ def lib():
             f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                           ctypes.c_size_t, ctypes.c_size_t]
     return _lib
+
+
+def erfi(z):
+    """erfi of a complex number as the oracle (and the device) evaluates it."""
+    out = (ctypes.c_double*2)()
+    lib().gfi_erfi(float(z.real), float(z.imag), out)
+    return complex(out[0], out[1])
 
 
 class Item:

@@ -259,6 +259,66 @@ void gfi_random_states(gfi_mt_state *states, const size_t count, const uint32_t 
     }
 }
 
+/* erfi(z) for complex z as graph_framework_amd/csrc/prelude.hpp evaluates it: -i erf(iz),
+ * erf(u) = 1 - exp(-u^2) w(iu), w by Weideman's N = 48 rational approximation (SIAM J. Numer. Anal.
+ * 31 (1994) 1497).  The reference's special::erfi (special_functions.hpp:1583) is pinned by its own
+ * fixture graph_tests/test_erfi.nc at 2e-14 (erfi_test.cpp:20-83); tests/test_oracle.py holds this
+ * restatement to the same fixture and tolerance. */
+static double gfi_weideman[48], gfi_weideman_l = 0.0;
+static void gfi_weideman_init(void) {
+    const int n = 48, m = 2*n, m2 = 2*m;
+    const long double pi = 3.141592653589793238462643383279502884L;
+    const long double l = sqrtl((long double)n/sqrtl(2.0L));
+    long double f[192];
+    f[0] = 0.0L;
+    for (int j = 1; j < m2; j++) {
+        const long double t = l*tanl((j - m)*pi/m/2.0L);
+        f[j] = expl(-t*t)*(l*l + t*t);
+    }
+    for (int k = 1; k <= n; k++) {
+        long double sum = 0.0L;
+        for (int j = 0; j < m2; j++) sum += f[(j + m2/2)%m2]*cosl(2.0L*pi*k*j/m2);
+        gfi_weideman[k - 1] = (double)(sum/m2);
+    }
+    gfi_weideman_l = (double)l;
+}
+typedef struct { double re, im; } gfi_z;
+static inline gfi_z gfi_zmul(const gfi_z a, const gfi_z b) { gfi_z v = {a.re*b.re - a.im*b.im, a.re*b.im + a.im*b.re}; return v; }
+static inline gfi_z gfi_zdiv(const gfi_z a, const gfi_z b) {
+    const double d = b.re*b.re + b.im*b.im;
+    gfi_z v = {(a.re*b.re + a.im*b.im)/d, (a.im*b.re - a.re*b.im)/d};
+    return v;
+}
+static inline gfi_z gfi_zexp(const gfi_z a) { const double e = exp(a.re); gfi_z v = {e*cos(a.im), e*sin(a.im)}; return v; }
+static gfi_z gfi_faddeeva_upper(const gfi_z z) {
+    const gfi_z down = {gfi_weideman_l + z.im, -z.re}, up = {gfi_weideman_l - z.im, z.re};
+    const gfi_z big = gfi_zdiv(up, down);
+    gfi_z p = {gfi_weideman[47], 0.0};
+    for (int k = 46; k >= 0; k--) {
+        p = gfi_zmul(p, big);
+        p.re += gfi_weideman[k];
+    }
+    const gfi_z twice = {2.0*p.re, 2.0*p.im}, scale = {0x1.20dd750429b6dp-1, 0.0};
+    const gfi_z first = gfi_zdiv(twice, gfi_zmul(down, down)), second = gfi_zdiv(scale, down);
+    gfi_z v = {first.re + second.re, first.im + second.im};
+    return v;
+}
+static gfi_z gfi_faddeeva(const gfi_z z) {
+    if (z.im >= 0.0) return gfi_faddeeva_upper(z);
+    const gfi_z square = gfi_zmul(z, z), minus = {-square.re, -square.im}, mirrored = {-z.re, -z.im};
+    const gfi_z e = gfi_zexp(minus), w = gfi_faddeeva_upper(mirrored);
+    gfi_z v = {2.0*e.re - w.re, 2.0*e.im - w.im};
+    return v;
+}
+void gfi_erfi(const double re, const double im, double *out) {
+    if (gfi_weideman_l == 0.0) gfi_weideman_init();
+    const gfi_z z = {re, im}, mirrored = {-re, -im};
+    const gfi_z e = gfi_zexp(gfi_zmul(z, z)), w = gfi_faddeeva(mirrored);
+    const double erf_re = 1.0 - (e.re*w.re - e.im*w.im), erf_im = -(e.re*w.im + e.im*w.re);
+    out[0] = erf_im;
+    out[1] = -erf_re;
+}
+
 #define DEFINE_GENERIC(SUFFIX, REAL, TABLES, FMA, SQRT, POW, SIN, COS, ATAN2, EXP, LOG, FMIN, FMAX, FABS, HYPOT, SINH, COSH, BIG) \
 typedef struct { REAL re, im; } gfi_value_##SUFFIX;                                                      \
 static inline gfi_value_##SUFFIX gfi_mul_##SUFFIX(const gfi_value_##SUFFIX a, const gfi_value_##SUFFIX b, const int cx) { \
@@ -362,6 +422,12 @@ void gfi_run_generic_##SUFFIX(const gfi_item *item, REAL **columns, REAL **outs,
                 case GFIR_LOG:                                                                           \
                     if (cx) v = gfi_clog_##SUFFIX(a); else v.re = LOG(a.re);                             \
                     break;                                                                               \
+                case GFIR_ERFI: {                                                                        \
+                    double parts2[2];                                                                    \
+                    gfi_erfi((double)a.re, (double)a.im, parts2);                                        \
+                    v.re = (REAL)parts2[0]; v.im = (REAL)parts2[1];                                      \
+                    break;                                                                               \
+                }                                                                                        \
                 case GFIR_GATHER1: {                                                                     \
                     const size_t at = gfi_gindex_##SUFFIX(a, (REAL)c->imm[0], (REAL)c->imm[1], item->table_cols[c->aux], cx); \
                     v.re = item->TABLES[c->aux][at*parts]; v.im = cx ? item->TABLES[c->aux][at*parts + 1] : 0; \

@@ -108,6 +108,17 @@ def main():
     np.savez_compressed(os.path.join(HERE, "efit_tables.npz"), **read_efit(os.path.join(HERE, "efit.nc")))
     np.savez_compressed(os.path.join(HERE, "efit_gold.npz"), **read_gold(os.path.join(HERE, "efit_gold.nc")))
     print("wrote efit_tables.npz, efit_gold.npz")
+    if os.path.exists("/root/reference/graph_tests/test_erfi.nc"):
+        erfi_fixture()
+        print("wrote test_erfi.npz")
+
+
+def erfi_fixture(reference="/root/reference"):
+    """graph_tests/test_erfi.nc (the reference-held fixture of special::erfi: a 16 x 16 grid of
+    z = x + iy on [-10, 10]^2 with erfi(z) = re + i img) as tests/golden/test_erfi.npz."""
+    f = H5File(os.path.join(reference, "graph_tests", "test_erfi.nc"))
+    np.savez_compressed(os.path.join(HERE, "test_erfi.npz"), x=f.read("x"), y=f.read("y"), re=f.read("re"), img=f.read("img"))
+    f.close()
 
 
 if __name__ == "__main__":

@@ -282,3 +282,37 @@ def test_result_file_has_the_reference_netcdf4_dimensions(tmp_path):
         for r in range(4):
             np.testing.assert_array_equal(data[r, :, 0], records[r][name])
     f.close()
+
+
+def test_cli_distribution_draws_the_reference_samples(lib, tmp_path):
+    """graph_framework_amd.xrays.cli_distribution restates std::mt19937_64 and libstdc++'s
+    std::normal_distribution by hand (csrc/cli_distribution.cpp): its samples are, bit for bit,
+    those of the real objects in the reference's draw order (graph_driver/xrays.cpp:397-453) —
+    committed samples (tests/golden/cli_distribution_golden.npz, make_cli_fixture.cpp) and, where
+    g++ is present, a fresh run of the real objects."""
+    import subprocess
+    from conftest import GOLDEN
+    from graph_framework_amd.xrays import cli_distribution
+    golden = np.load(os.path.join(GOLDEN, "cli_distribution_golden.npz"))
+    shard = int(golden["shard"])
+    for seed in golden["seeds"]:
+        rays = cli_distribution(shard, seed=int(seed))
+        phi = np.arctan2(rays["y"], rays["x"])
+        for name in ("w", "ky", "kz", "z"):
+            index = golden["seed%d_%s_index" % (seed, name)]
+            assert np.array_equal(rays[name][index], golden["seed%d_%s" % (seed, name)]), (seed, name)
+        index = golden["seed%d_phi_index" % seed]
+        want = golden["seed%d_phi" % seed]
+        assert np.array_equal(rays["x"][index], 2.5*np.cos(want)) and np.array_equal(rays["y"][index], 2.5*np.sin(want))
+        assert np.allclose(phi[index], want, rtol=0, atol=1.0e-15)
+        assert np.all(rays["kx"] == -700.0) and np.all(rays["t"] == 0.0)
+    source = os.path.join(GOLDEN, "make_cli_fixture.cpp")
+    binary = str(tmp_path / "make_cli_fixture")
+    if subprocess.run(["g++", "-O1", "-o", binary, source]).returncode == 0:
+        text = subprocess.run([binary, "5000", "5000"], capture_output=True, text=True, check=True).stdout
+        rays = cli_distribution(5000, seed=1)
+        live = {v: np.array([float.fromhex(l.split()[3]) for l in text.splitlines() if l.startswith("1 %d " % v)][:5000])
+                for v in range(5)}
+        for v, name in ((0, "w"), (1, "ky"), (2, "kz"), (3, "z")):
+            assert np.array_equal(rays[name], live[v]), name
+        assert np.array_equal(rays["x"], 2.5*np.cos(live[4]))

@@ -18,7 +18,7 @@ from oracle import gfir
 pytestmark = pytest.mark.gpu
 
 N = 0xFFFFFFFF
-CONST, INPUT, ADD, SUB, MUL, DIV, FMA, SQRT, POWI, POW, SIN, COS, ATAN2, EXP, LOG, GATHER1, GATHER2, INDEX1, INDEX2, RANDOM = range(20)
+CONST, INPUT, ADD, SUB, MUL, DIV, FMA, SQRT, POWI, POW, SIN, COS, ATAN2, EXP, LOG, GATHER1, GATHER2, INDEX1, INDEX2, RANDOM, ERFI = range(21)
 DTYPES = {"f32": 0, "f64": 1, "c32": 2, "c64": 3}
 NUMPY = {"f32": np.float32, "f64": np.float64, "c32": np.complex64, "c64": np.complex128}
 
@@ -197,4 +197,36 @@ def test_complex_converge_item_takes_the_element_of_largest_modulus():
     context.compile()
     kernel.create_kernel_call(["z"], ["zz"], [values])
     assert kernel.run_max_complex() == (3.0 - 4.0j)**2
+    context.close()
+
+
+@pytest.mark.parametrize("dtype,tolerance", [("c64", 2.0e-14), ("c32", 2.0e-5)])
+def test_erfi_on_the_device_meets_the_reference_erfi_test(dtype, tolerance):
+    """erfi_node (math.hpp:1440) on the device against the reference-held fixture of special::erfi
+    (graph_tests/test_erfi.nc, tests/golden/test_erfi.npz) with the rule and the tolerances of
+    graph_tests/erfi_test.cpp:50-83, :89-90 (2e-14 double, 2e-5 float)."""
+    import os
+    from conftest import GOLDEN
+    from graph_framework_amd import Context
+    fixture = np.load(os.path.join(GOLDEN, "test_erfi.npz"))
+    it = Item(dtype, False, ["z"], name="erfi")
+    blob = it.blob([it.emit(ERFI, it.emit(INPUT, a=0))], [])
+    real = NUMPY[dtype]
+    z = (fixture["x"] + 1j*fixture["y"]).astype(real)
+    context = Context(0)
+    kernel = context.add_kernel(blob, z.size)
+    context.compile()
+    kernel.create_kernel_call(["z"], ["erfi"], [z])
+    kernel.run(1)
+    context.wait()
+    got = context.copy_to_host("erfi", np.empty(z.size, dtype=real))
+    gold = fixture["re"] + 1j*fixture["img"]
+    if dtype == "c32":                                   # float: the arguments the device saw
+        gold = np.array([gfir.erfi(complex(v)) for v in z])
+    with np.errstate(all="ignore"):
+        error = np.abs(1.0 - got[5:].astype(np.complex128)/gold[5:])
+    finite = np.isfinite(gold[5:].real) & np.isfinite(gold[5:].imag) & np.isfinite(got[5:].real) & np.isfinite(got[5:].imag)
+    assert finite.sum() > 200 and error[finite].max() <= tolerance, error[finite].max()
+    oracle_values, _ = gfir.Item(blob).run([z.copy()])
+    np.testing.assert_allclose(got, oracle_values[0], rtol=1.0e-13 if dtype == "c64" else 1.0e-5, atol=0.0)
     context.close()

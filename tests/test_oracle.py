@@ -271,3 +271,20 @@ def test_adaptive_rk4_on_the_oracle_matches_the_reference_graph_layer():
                 assert np.array_equal(columns[c], record[c], equal_nan=True), (step, c)
             assert np.array_equal(outs[0], record[10], equal_nan=True)
     assert int(golden["records"][1, 11, 0]) == 22 and np.isnan(golden["records"][1, 2]).all()
+
+
+def test_erfi_restatement_meets_the_reference_erfi_test():
+    """special::erfi (special_functions.hpp:1583) is pinned by the reference-held fixture
+    graph_tests/test_erfi.nc (tests/golden/test_erfi.npz) through graph_tests/erfi_test.cpp:50-83:
+    |1 - test/gold| <= 2e-14 from the sixth point on.  The restatement the oracle and the device
+    share (Weideman's N = 48 rational approximation of the Faddeeva function) is held to the same
+    fixture, rule and tolerance."""
+    from oracle import gfir
+    fixture = np.load(os.path.join(GOLDEN, "test_erfi.npz"))
+    worst = 0.0
+    for i in range(5, fixture["x"].size):
+        gold = complex(fixture["re"][i], fixture["img"][i])
+        test = gfir.erfi(complex(fixture["x"][i], fixture["y"][i]))
+        assert np.isfinite(gold.real) and np.isfinite(gold.imag)
+        worst = max(worst, abs(1.0 - test/gold))
+    assert worst <= 2.0e-14, worst
