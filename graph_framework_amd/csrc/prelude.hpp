@@ -195,8 +195,20 @@ __device__ inline gf_z gf_faddeeva(const gf_z z) {
     const gf_z w = gf_faddeeva_upper(gf_z{-z.re, -z.im});
     return gf_z{2.0*e.re - w.re, 2.0*e.im - w.im};
 }
+// The branches special::erf_complex takes before its general formula (special_functions.hpp:1495-1517),
+// as behaviour: on the imaginary axis i erf(Im z); on the real axis the REAL value exp(x^2) Im w(x),
+// saturated beyond x^2 = 720 (Im Z(zeta) = sqrt(pi) exp(-zeta^2) then keeps its relative accuracy in
+// dispersion.hpp:289-297); Re(z^2) < -750 gives -+i.
 __device__ inline gf_complex gf_erfi(const gf_complex a) {
     const gf_z z{static_cast<double> (a.re), static_cast<double> (a.im)};
+    if (z.re == 0.0) return gf_complex(a.re, static_cast<base> (erf(z.im)));
+    if (z.im == 0.0) {
+        const double on_axis = z.re*z.re > 720.0 ? copysign(__DBL_MAX__, z.re)
+                                                 : exp(z.re*z.re)*gf_faddeeva_upper(gf_z{z.re, 0.0}).im;
+        return gf_complex(static_cast<base> (on_axis), a.im);
+    }
+    if (isinf(z.re) && isinf(z.im)) return gf_complex(static_cast<base> (0), static_cast<base> (-0.0));
+    if ((z.re + z.im)*(z.re - z.im) < -750.0) return gf_complex(static_cast<base> (0), static_cast<base> (z.im <= 0.0 ? -1.0 : 1.0));
     const gf_z e = gf_zexp(gf_zmul(z, z));                                       // exp(-u^2), u = iz
     const gf_z w = gf_faddeeva(gf_z{-z.re, -z.im});                              // w(iu) = w(-z)
     const gf_z erf{1.0 - (e.re*w.re - e.im*w.im), -(e.re*w.im + e.im*w.re)};    // erf(iz)

@@ -210,10 +210,8 @@ private:
             i.imm[2] = real_part(x->get_y_scale());
             i.imm[3] = real_part(x->get_y_offset());
             slot = emit(i);
-        } else if (auto x = graph::erfi_cast(n); x.get()) {
-            gfir_instruction i = blank(GFIR_ERFI);
-            i.a = lower(x->get_arg());
-            slot = emit(i);
+        } else if (const uint32_t e = erfi(n); e != none) {
+            slot = e;
         } else if (auto x = graph::index_1D_cast(n); x.get()) {
 //  v[idx(arg)]: the argument is compiled first, the variable is only named (piecewise.hpp:1530-1575).
             gfir_instruction i = blank(GFIR_INDEX1);
@@ -241,6 +239,19 @@ private:
         }
         slots[n.get()] = slot;
         return slot;
+    }
+
+//  erfi nodes exist for complex base types only (math.hpp:1439, :1661).
+    static constexpr uint32_t none = 0xffffffffu;
+    uint32_t erfi(graph::shared_leaf<T, SAFE_MATH> n) {
+        if constexpr (jit::complex_scalar<T>) {
+            if (auto x = graph::erfi_cast(n); x.get()) {
+                gfir_instruction i = blank(GFIR_ERFI);
+                i.a = lower(x->get_arg());
+                return emit(i);
+            }
+        }
+        return none;
     }
 
     uint32_t draw() {

@@ -36,6 +36,7 @@ _H5T_STR_NULLTERM = 0
 _NON_COORDINATE = "_nc4_non_coord_"
 _DIMENSION_NAME = "This is a netCDF dimension but not a netCDF variable.%10d"
 _H5F_ACC_TRUNC = 2
+_H5F_ACC_RDWR = 1
 _H5S_SELECT_SET = 0
 _H5S_UNLIMITED = 0xFFFFFFFFFFFFFFFF
 
@@ -77,6 +78,13 @@ def _hdf5():
     lib.H5Acreate2.restype = hid
     lib.H5Acreate2.argtypes = [hid, ctypes.c_char_p, hid, hid, hid, hid]
     lib.H5Awrite.argtypes = [hid, hid, ctypes.c_void_p]
+    lib.H5Fopen.restype = hid
+    lib.H5Fopen.argtypes = [ctypes.c_char_p, ctypes.c_uint, hid]
+    lib.H5Dopen2.restype = hid
+    lib.H5Dopen2.argtypes = [hid, ctypes.c_char_p, hid]
+    lib.H5Dread.argtypes = [hid, hid, hid, hid, hid, ctypes.c_void_p]
+    lib.H5Sget_simple_extent_dims.argtypes = [hid, ctypes.c_void_p, ctypes.c_void_p]
+    lib.H5Lexists.argtypes = [hid, ctypes.c_char_p, hid]
     lib.H5open()
     for name in _HL_CANDIDATES:
         try:
@@ -96,9 +104,12 @@ class ResultFile:
     (unlimited), num_rays, ray_dim; variables of shape (time, num_rays, ray_dim); one record
     appended per write."""
 
-    def __init__(self, path, num_rays, dtype=np.float64):
+    def __init__(self, path, num_rays=None, dtype=np.float64):
+        """num_rays given: result_file(filename, num_rays), output.hpp:50-66 — a new file.
+        num_rays None: result_file(filename), output.hpp:77-86 — an existing file opened for
+        update (the absorption pass and bin_power add their variables to the trajectory file)."""
         self.lib = _hdf5()
-        self.num_rays = int(num_rays)
+        self.lock = threading.Lock()                         # output::sync (output.hpp:21): libhdf5 calls are serialised
         self.dtype = np.dtype(dtype)
         hid = ctypes.c_int64
         native = "H5T_NATIVE_DOUBLE_g" if self.dtype == np.float64 else "H5T_NATIVE_FLOAT_g"
@@ -107,15 +118,46 @@ class ResultFile:
         self.string = hid.in_dll(self.lib, "H5T_C_S1_g").value
         self.scale_type = hid.in_dll(self.lib, "H5T_IEEE_F32BE_g").value
         self.dataset_create = hid.in_dll(self.lib, "H5P_CLS_DATASET_CREATE_ID_g").value
+        self.variables = {}
+        self.parts = {}
+        self.opened = {}
+        if num_rays is None:
+            self.file = self.lib.H5Fopen(path.encode(), _H5F_ACC_RDWR, 0)
+            if self.file < 0:
+                raise IOError("cannot open %s" % path)
+            self.dimensions = [self._open_dataset(name) for name in ("time", "num_rays", "ray_dim")]
+            self.records = self._extent(self.dimensions[0])[0]
+            self.num_rays = self._extent(self.dimensions[1])[0]
+            self.next_dimid = 3
+            self.complex_dimension = None
+            if self.lib.H5Lexists(self.file, b"ray_dim_cplx", 0) > 0:
+                self.complex_dimension = self._open_dataset("ray_dim_cplx")
+                self.next_dimid = 4
+            return
+        self.num_rays = int(num_rays)
         self.file = self.lib.H5Fcreate(path.encode(), _H5F_ACC_TRUNC, 0, 0)
         if self.file < 0:
             raise IOError("cannot create %s" % path)
-        self.variables = {}
         self.records = 0
         self._string_attribute(self.file, "_NCProperties", "version=2,graph_framework_amd=1,hdf5=1.10", None)
 #  result_file's constructor (output.hpp:61-64) and data_set's (output.hpp:189-197).
         self.dimensions = [self._dimension("time", None, 0), self._dimension("num_rays", max(self.num_rays, 1), 1),
                            self._dimension("ray_dim", 1, 2)]
+        self.next_dimid = 3
+        self.complex_dimension = None
+
+    def _open_dataset(self, name):
+        dataset = self.lib.H5Dopen2(self.file, name.encode(), 0)
+        if dataset < 0:
+            raise IOError("no dataset %s in the file" % name)
+        return dataset
+
+    def _extent(self, dataset):
+        space = self.lib.H5Dget_space(dataset)
+        dims = (ctypes.c_uint64*3)()
+        self.lib.H5Sget_simple_extent_dims(space, dims, None)
+        self.lib.H5Sclose(space)
+        return list(dims)
 
     def _string_attribute(self, where, name, text, size):
         data = text.encode()
@@ -166,51 +208,98 @@ class ResultFile:
         self._int_attribute(dataset, "_Netcdf4Dimid", [dimid])
         return dataset
 
-    def create_variable(self, name):
-        """data_set::create_variable (output.hpp:260-273): nc_def_var(name, type, {time, num_rays, ray_dim})."""
-        dims = (ctypes.c_uint64*3)(0, self.num_rays, 1)
-        maxdims = (ctypes.c_uint64*3)(_H5S_UNLIMITED, self.num_rays, 1)
-        chunk = (ctypes.c_uint64*3)(1, max(self.num_rays, 1), 1)
+    @staticmethod
+    def _stored_name(name):
+#  A variable that shares a dimension's name without being its coordinate variable.
+        return _NON_COORDINATE + name if name in ("time", "num_rays", "ray_dim") else name
+
+    def create_variable(self, name, parts=1):
+        """data_set::create_variable (output.hpp:260-273): nc_def_var(name, type, {time, num_rays, ray_dim}).
+        parts = 2: a variable of a complex data_set, whose last dimension is `ray_dim_cplx` of length 2
+        (real, imaginary; output.hpp:215-224)."""
+        last = self.dimensions[2]
+        last_id = 2
+        if parts == 2:
+            if self.complex_dimension is None:
+                self.complex_dimension = self._dimension("ray_dim_cplx", 2, self.next_dimid)
+                self.next_dimid += 1
+            last = self.complex_dimension
+            last_id = self.next_dimid - 1
+        dims = (ctypes.c_uint64*3)(self.records, self.num_rays, parts)
+        maxdims = (ctypes.c_uint64*3)(_H5S_UNLIMITED, self.num_rays, parts)
+        chunk = (ctypes.c_uint64*3)(1, max(self.num_rays, 1), parts)
         space = self.lib.H5Screate_simple(3, dims, maxdims)
         plist = self.lib.H5Pcreate(self.dataset_create)
         self.lib.H5Pset_chunk(plist, 3, chunk)
-#  A variable that shares a dimension's name without being its coordinate variable.
-        stored = _NON_COORDINATE + name if name in ("time", "num_rays", "ray_dim") else name
-        dataset = self.lib.H5Dcreate2(self.file, stored.encode(), self.native, space, 0, plist, 0)
+        dataset = self.lib.H5Dcreate2(self.file, self._stored_name(name).encode(), self.native, space, 0, plist, 0)
         self.lib.H5Pclose(plist)
         self.lib.H5Sclose(space)
         if dataset < 0:
             raise IOError("cannot create variable %s" % name)
-        for index, scale in enumerate(self.dimensions):
+        for index, scale in enumerate((self.dimensions[0], self.dimensions[1], last)):
             if self.lib.hl.H5DSattach_scale(dataset, scale, index) < 0:
                 raise IOError("H5DSattach_scale failed for %s" % name)
-        self._int_attribute(dataset, "_Netcdf4Coordinates", [0, 1, 2])
+        self._int_attribute(dataset, "_Netcdf4Coordinates", [0, 1, last_id])
         self.variables[name] = dataset
+        self.parts[name] = parts
 
-    def write(self, record):
-        """Append one record: {variable: array of num_rays} (data_set::write, output.hpp:354-400)."""
-        extent = (ctypes.c_uint64*3)(self.records + 1, self.num_rays, 1)
-        start = (ctypes.c_uint64*3)(self.records, 0, 0)
-        count = (ctypes.c_uint64*3)(1, self.num_rays, 1)
-        mem_dims = (ctypes.c_uint64*3)(1, self.num_rays, 1)
+    def _hyperslab(self, dataset, index, part, parts):
+        start = (ctypes.c_uint64*3)(index, 0, part)
+        count = (ctypes.c_uint64*3)(1, self.num_rays, parts)
+        file_space = self.lib.H5Dget_space(dataset)
+        self.lib.H5Sselect_hyperslab(file_space, _H5S_SELECT_SET, start, None, count, None)
+        mem_space = self.lib.H5Screate_simple(3, count, None)
+        return file_space, mem_space
+
+    def write(self, record, index=None):
+        """data_set::write (output.hpp:354-400): one record {variable: array of num_rays} (complex arrays
+        for variables created with parts = 2), appended, or at time index `index` (output.hpp:363)."""
+        with self.lock:
+            self._write(record, index)
+
+    def _write(self, record, index):
+        at = self.records if index is None else int(index)
         for name, dataset in self.variables.items():
-            values = np.ascontiguousarray(record[name], dtype=self.dtype)
+            parts = self.parts[name]
+            values = np.ascontiguousarray(record[name], dtype=np.complex128 if parts == 2 and self.dtype == np.float64
+                                          else (np.complex64 if parts == 2 else self.dtype))
             assert values.size == self.num_rays
-            self.lib.H5Dset_extent(dataset, extent)
-            file_space = self.lib.H5Dget_space(dataset)
-            self.lib.H5Sselect_hyperslab(file_space, _H5S_SELECT_SET, start, None, count, None)
-            mem_space = self.lib.H5Screate_simple(3, mem_dims, None)
+            if self._extent(dataset)[0] < at + 1:
+                self.lib.H5Dset_extent(dataset, (ctypes.c_uint64*3)(at + 1, self.num_rays, parts))
+            file_space, mem_space = self._hyperslab(dataset, at, 0, parts)
             status = self.lib.H5Dwrite(dataset, self.native, mem_space, file_space, 0, values.ctypes.data)
             self.lib.H5Sclose(mem_space)
             self.lib.H5Sclose(file_space)
             if status < 0:
                 raise IOError("H5Dwrite failed for %s" % name)
-        self.records += 1
-        self.lib.H5Dset_extent(self.dimensions[0], (ctypes.c_uint64*1)(self.records))    # the length of `time`
+        if at + 1 > self.records:
+            self.records = at + 1
+            self.lib.H5Dset_extent(self.dimensions[0], (ctypes.c_uint64*1)(self.records))    # the length of `time`
+        self.lib.H5Fflush(self.file, 1)                      # result.sync_file(), output.hpp:399
+
+    def read(self, name, index, part=0):
+        """data_set::read of one referenced variable (output.hpp:285-350, :412-470): the values of `name`
+        at time index `index`; part = 1 reads the imaginary part of a complex variable
+        (reference_imag_variable)."""
+        values = np.empty(self.num_rays, dtype=self.dtype)
+        with self.lock:
+            if name not in self.opened:
+                self.opened[name] = self.variables.get(name) or self._open_dataset(self._stored_name(name))
+            dataset = self.opened[name]
+            file_space, mem_space = self._hyperslab(dataset, int(index), part, 1)
+            status = self.lib.H5Dread(dataset, self.native, mem_space, file_space, 0, values.ctypes.data)
+            self.lib.H5Sclose(mem_space)
+            self.lib.H5Sclose(file_space)
+        if status < 0:
+            raise IOError("H5Dread failed for %s" % name)
+        return values
 
     def close(self):
         if self.file is not None:
-            for dataset in list(self.variables.values()) + self.dimensions:
+            extra = [d for name, d in self.opened.items() if name not in self.variables]
+            if self.complex_dimension is not None:
+                extra.append(self.complex_dimension)
+            for dataset in list(self.variables.values()) + self.dimensions + extra:
                 self.lib.H5Dclose(dataset)
             self.lib.H5Fclose(self.file)
             self.file = None

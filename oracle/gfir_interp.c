@@ -312,6 +312,20 @@ static gfi_z gfi_faddeeva(const gfi_z z) {
 }
 void gfi_erfi(const double re, const double im, double *out) {
     if (gfi_weideman_l == 0.0) gfi_weideman_init();
+/*  The branches special::erf_complex takes before its general formula (special_functions.hpp:1495-1517),
+ *  as behaviour: an argument on the imaginary axis gives i erf(Im z); an argument on the real axis gives a
+ *  REAL value exp(x^2) Im w(x), saturated at the largest double beyond x^2 = 720 (so that
+ *  Im Z(zeta) = sqrt(pi) exp(-zeta^2) keeps its relative accuracy in dispersion.hpp:289-297);
+ *  Re(z^2) < -750 gives -+i. */
+    if (re == 0.0) { out[0] = re; out[1] = erf(im); return; }
+    if (im == 0.0) {
+        const gfi_z on_axis = {re, 0.0};
+        out[0] = re*re > 720.0 ? copysign(1.7976931348623157e308, re) : exp(re*re)*gfi_faddeeva_upper(on_axis).im;
+        out[1] = im;
+        return;
+    }
+    if (isinf(re) && isinf(im)) { out[0] = 0.0; out[1] = -0.0; return; }
+    if ((re + im)*(re - im) < -750.0) { out[0] = 0.0; out[1] = im <= 0.0 ? -1.0 : 1.0; return; }
     const gfi_z z = {re, im}, mirrored = {-re, -im};
     const gfi_z e = gfi_zexp(gfi_zmul(z, z)), w = gfi_faddeeva(mirrored);
     const double erf_re = 1.0 - (e.re*w.re - e.im*w.im), erf_im = -(e.re*w.im + e.im*w.re);

@@ -618,6 +618,72 @@ static int cmd_export_misc(const std::string dir, const std::string suffix) {
     return 0;
 }
 
+//  weak_damping <in: kamp kx ky kz x y z t w (real columns)> <out: re(kamp) im(kamp)> <gfir path|->
+//  The absorption item of xrays (absorption.hpp:346-432) on complex<double>, SAFE_MATH = true, evaluated
+//  on the tape in the host's std::complex arithmetic (what a cpu_context kernel is written in) with the
+//  reference's own special::erfi; the input columns become the real parts (output.hpp:412-470 reads the
+//  real trajectory variables into complex buffers with stride 2).
+static int cmd_weak_damping(const raw_tables &raw, const char *in_path, const char *out_path, const char *gfir_path) {
+    typedef std::complex<double> T;
+    size_t n;
+    auto cols = read_columns(in_path, 9, n);
+    efit<T, true> eq(raw);
+    std::vector<leaf<T, true>> debug;
+    if (getenv("GF_REF_DEBUG")) absorption_debug<T, true> = &debug;
+    weak_damping_item<T, true> built(eq);
+    std::vector<leaf<T, true>> in(built.inputs.begin(), built.inputs.end());
+    std::vector<std::pair<leaf<T, true>, leaf<T, true>>> set;
+    for (auto &s : built.setters) set.push_back({s.first, s.second});
+    work_item<T, true> item(in, debug, set);
+    item.code.print_counts(stderr);
+    if (std::string(gfir_path) != "-") {
+        item.write_gfir("weak_damping_kimg_kernel", gfir_path);
+    }
+    std::vector<std::vector<T>> columns;
+    for (auto &c : cols) columns.emplace_back(c.begin(), c.end());
+    std::vector<std::vector<T>> debug_values(debug.size(), std::vector<T> (n));
+    item.run(n, pointers(columns, 0, 9), pointers(debug_values, 0, debug.size()));
+    for (size_t d = 0; d < debug.size(); d++) {
+        fprintf(stderr, "debug %zu: (%g, %g)\n", d, std::real(debug_values[d][0]), std::imag(debug_values[d][0]));
+    }
+    std::vector<std::vector<double>> out(2, std::vector<double> (n));
+    for (size_t i = 0; i < n; i++) {
+        out[0][i] = std::real(columns[0][i]);
+        out[1][i] = std::imag(columns[0][i]);
+    }
+    write_columns(out_path, out);
+    return 0;
+}
+
+//  power <in: x y z x_last y_last z_last kamp power k_sum, then `records` blocks of (x y z kamp)> <out> <records> <gfir|->
+//  bin_power's loop (graph_driver/xrays.cpp:745-775): per record copy x, y, z, kamp in, run the `power`
+//  item once.  out: per record (power, d_power, k_sum).
+template<typename T>
+static int cmd_power(const char *in_path, const char *out_path, const size_t records, const char *gfir_path) {
+    size_t n;
+    auto cols = convert<T> (read_columns(in_path, 9 + 4*records, n));
+    power_item<T> p;
+    std::vector<leaf<T>> in(p.inputs.begin(), p.inputs.end());
+    std::vector<std::pair<leaf<T>, leaf<T>>> set;
+    for (auto &s : p.setters) set.push_back({s.first, s.second});
+    work_item<T> item(in, {p.d_power}, set);
+    if (std::string(gfir_path) != "-") {
+        item.write_gfir("power", gfir_path);
+    }
+    std::vector<T> d_power(n);
+    std::vector<std::vector<T>> out;
+    for (size_t r = 0; r < records; r++) {
+        for (size_t c = 0; c < 3; c++) cols[c] = cols[9 + 4*r + c];
+        cols[6] = cols[9 + 4*r + 3];
+        item.run(n, pointers(cols, 0, 9), {d_power.data()});
+        out.push_back(cols[7]);
+        out.push_back(d_power);
+        out.push_back(cols[8]);
+    }
+    write_columns(out_path, to_double(out));
+    return 0;
+}
+
 template<typename T>
 static int dispatch(const raw_tables &raw, int argc, char **argv) {
     const std::string cmd = argv[3];
@@ -654,6 +720,8 @@ static int dispatch(const raw_tables &raw, int argc, char **argv) {
                              strtoull(argv[8], nullptr, 10), atoi(argv[9]));
     } else if (cmd == "trace_adaptive" && argc == 9) {
         return cmd_trace_adaptive<T> (raw, argv[4], argv[5], strtoull(argv[6], nullptr, 10), argv[7], argv[8]);
+    } else if (cmd == "power" && argc == 8) {
+        return cmd_power<T> (argv[4], argv[5], strtoull(argv[6], nullptr, 10), argv[7]);
     } else if (cmd == "export_misc" && argc == 6) {
         return cmd_export_misc<T> (argv[4], argv[5]);
     } else if (cmd == "export_korc" && argc == 6) {
@@ -675,6 +743,13 @@ int main(int argc, char **argv) {
         return 2;
     }
     const raw_tables raw(argv[1]);
+    if (std::string(argv[2]) == "c64") {
+        if (std::string(argv[3]) == "weak_damping" && argc == 7) {
+            return cmd_weak_damping(raw, argv[4], argv[5], argv[6]);
+        }
+        fprintf(stderr, "bad command\n");
+        return 2;
+    }
     if (std::string(argv[2]) == "f32") {
         return dispatch<float> (raw, argc, argv);
     }

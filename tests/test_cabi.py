@@ -316,3 +316,47 @@ def test_cli_distribution_draws_the_reference_samples(lib, tmp_path):
         for v, name in ((0, "w"), (1, "ky"), (2, "kz"), (3, "z")):
             assert np.array_equal(rays[name], live[v]), name
         assert np.array_equal(rays["x"], 2.5*np.cos(live[4]))
+
+
+def test_result_file_is_reopened_for_the_absorption_variables(tmp_path):
+    """result_file(filename) (output.hpp:77-86) + a complex data_set (:215-224): the absorption pass
+    opens the trajectory file for update, adds `kamp` over (time, num_rays, ray_dim_cplx = 2), reads
+    the ray variables by time index and writes kamp at that index; bin_power reads its imaginary
+    part (reference_imag_variable, :321-347) and adds `power`."""
+    import subprocess
+    from graph_framework_amd.output import ResultFile
+    path = str(tmp_path / "result0.nc")
+    n = 6
+    out = ResultFile(path, n)
+    for name in ("time", "x"):
+        out.create_variable(name)
+    for record in range(4):
+        out.write({"time": np.full(n, 0.25*record), "x": np.arange(n) + 10.0*record})
+    out.close()
+
+    update = ResultFile(path)
+    assert (update.num_rays, update.records) == (n, 4)
+    update.create_variable("kamp", parts=2)
+    for record in range(4):
+        x = update.read("x", record)
+        np.testing.assert_array_equal(x, np.arange(n) + 10.0*record)
+        update.write({"kamp": x + 1j*(record + 0.5)}, index=record)
+    update.close()
+
+    again = ResultFile(path)
+    assert again.records == 4                                          # indexed writes do not grow `time`
+    again.create_variable("power")
+    for record in range(4):
+        np.testing.assert_array_equal(again.read("kamp", record, part=1), np.full(n, record + 0.5))
+        np.testing.assert_array_equal(again.read("kamp", record), np.arange(n) + 10.0*record)
+        np.testing.assert_array_equal(again.read("time", record), np.full(n, 0.25*record))
+        again.write({"power": np.full(n, 1.0/(record + 1))}, index=record)
+    again.close()
+
+    h5dump = "/opt/conda/bin/h5dump"
+    if os.path.exists(h5dump):
+        flat = " ".join(subprocess.run([h5dump, "-H", "-A", path], capture_output=True, text=True, check=True).stdout.split())
+        assert 'DATASET "ray_dim_cplx" { DATATYPE H5T_IEEE_F32BE DATASPACE SIMPLE { ( 2 ) / ( 2 ) }' in flat
+        assert 'DATASET "kamp" { DATATYPE H5T_IEEE_F64LE DATASPACE SIMPLE { ( 4, 6, 2 ) / ( H5S_UNLIMITED, 6, 2 ) }' in flat
+        assert 'DATASET "power" { DATATYPE H5T_IEEE_F64LE DATASPACE SIMPLE { ( 4, 6, 1 ) / ( H5S_UNLIMITED, 6, 1 ) }' in flat
+        assert flat.count('"DIMENSION_SCALE"') == 4

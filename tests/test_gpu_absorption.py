@@ -1,0 +1,98 @@
+"""The power-absorption pass of xrays on the device: the work item of
+absorption::weak_damping (complex<double>, SAFE_MATH, erfi; absorption.hpp:346-432) and bin_power's
+`power` item (graph_driver/xrays.cpp:674-790), through the C ABI, against the oracle and against the
+records of the reference's own graph layer (tests/golden/absorption_golden.npz,
+make_absorption_golden.py).
+
+Tolerances, stated: the device's complex arithmetic is specified operation by operation like the
+oracle's (textbook product, Smith's quotient, nothing fused), so the only differences are the
+device libm's exp/sin/cos/log/hypot against glibc's: 1e-12 relative in EACH part of kamp (imaginary
+parts run from 20 down to 1e-303).  Against the golden (std::complex arithmetic, the reference's
+special::erfi) the same bound holds.  `power` is real arithmetic with one exp() per record: 1e-14
+relative on power, 1e-15 absolute on d_power = |difference of two powers| on the same kamp.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, STATE, WORKLOADS
+from test_oracle import absorption_columns
+
+pytestmark = pytest.mark.gpu
+
+INPUTS = ("kamp", "kx", "ky", "kz", "x", "y", "z", "t", "w")
+
+
+def _close(got, want, rtol):
+    assert np.array_equal(got.imag == 0.0, want.imag == 0.0)
+    np.testing.assert_allclose(got.real, want.real, rtol=rtol, atol=0.0)
+    np.testing.assert_allclose(got.imag, want.imag, rtol=rtol, atol=0.0)
+
+
+def test_weak_damping_item_matches_the_oracle_and_the_reference_records():
+    from graph_framework_amd import Context
+    from oracle import gfir
+    golden = np.load(os.path.join(GOLDEN, "absorption_golden.npz"))
+    path = os.path.join(WORKLOADS, "weak_damping_kimg_kernel_c64.gfir")
+    columns = absorption_columns(golden["records"])
+    rays = columns[0].size
+    context = Context(0)
+    kernel = context.add_kernel(path, rays)
+    context.compile()
+    kernel.create_kernel_call(INPUTS, [], columns)
+    kernel.run(1)
+    context.wait()
+    got = context.copy_to_host("kamp", np.empty(rays, dtype=np.complex128))
+    for name, column in zip(INPUTS[1:], columns[1:]):                      # no other input is written
+        assert np.array_equal(context.copy_to_host(name, np.empty(rays, dtype=np.complex128)), column), name
+    context.close()
+    expected = [c.copy() for c in columns]
+    gfir.Item(path).run(expected, steps=1)
+    _close(got, expected[0], 1.0e-12)
+    _close(got, golden["kamp"].reshape(-1), 1.0e-12)
+    assert (got.imag > 1.0).any()
+
+
+def test_absorption_pass_over_a_trajectory_file(tmp_path):
+    """trace file -> WeakDamping (kamp added to the file) -> bin_power (power, d_power added): the
+    three-stage pipeline of graph_driver/xrays.cpp:1100-1105 on the golden trajectories."""
+    from graph_framework_amd.absorption import bin_power, run_absorption
+    from graph_framework_amd.output import RAY_VARIABLES, ResultFile
+    from oracle import gfir
+    golden = np.load(os.path.join(GOLDEN, "absorption_golden.npz"))
+    records = golden["records"]
+    saved, _, n = records.shape
+    path = str(tmp_path / "result0.nc")
+    trace = ResultFile(path, n)
+    for name, _ in RAY_VARIABLES:
+        trace.create_variable(name)
+    column = {k: i for i, k in enumerate(STATE + ("residual",))}
+    for r in range(saved):
+        trace.write({name: records[r, column[key]] for name, key in RAY_VARIABLES})
+    trace.close()
+
+    run_absorption(path, saved - 1)
+    bin_power(path, saved - 1)
+
+    result = ResultFile(path)
+    assert result.records == saved
+    kamp = np.stack([result.read("kamp", r) + 1j*result.read("kamp", r, part=1) for r in range(saved)])
+    power = np.stack([result.read("power", r) for r in range(saved)])
+    d_power = np.stack([result.read("d_power", r) for r in range(saved)])
+    result.close()
+    _close(kamp.reshape(-1), golden["kamp"].reshape(-1), 1.0e-12)
+    np.testing.assert_array_equal(power[0], np.ones(n))
+#  the `power` item on the device's own kamp, replayed on the oracle (device exp vs glibc's)
+    item = gfir.Item(os.path.join(WORKLOADS, "power_f64.gfir"))
+    first = [records[0, 2].copy(), records[0, 3].copy(), records[0, 4].copy()]
+    columns = [c.copy() for c in first] + first + [np.zeros(n), np.ones(n), np.zeros(n)]
+    for r in range(1, saved):
+        for c in range(3):
+            columns[c] = records[r, 2 + c].copy()
+        columns[6] = kamp[r].imag.copy()
+        outs, _ = item.run(columns, steps=1)
+        np.testing.assert_allclose(power[r], columns[7], rtol=1.0e-14, atol=0.0)
+        np.testing.assert_allclose(d_power[r], outs[0], rtol=1.0e-13, atol=1.0e-15)
+    np.testing.assert_allclose(power[1:], golden["power"][:, 0], rtol=1.0e-10, atol=0.0)
+    assert 0.0 < power[-1].min() and power[-1].max() < 0.5

@@ -288,3 +288,54 @@ def test_erfi_restatement_meets_the_reference_erfi_test():
         assert np.isfinite(gold.real) and np.isfinite(gold.imag)
         worst = max(worst, abs(1.0 - test/gold))
     assert worst <= 2.0e-14, worst
+
+
+ABSORPTION_INPUTS = ("kx", "ky", "kz", "x", "y", "z", "t", "w")
+
+
+def absorption_columns(records):
+    """The inputs of `weak_damping_kimg_kernel` (absorption.hpp:411-422) for every stored record of
+    the golden trajectories: kamp, then the real ray state in the real parts."""
+    saved, _, n = records.shape
+    flat = {k: records[:, i, :].reshape(-1) for i, k in enumerate(STATE)}
+    return [np.zeros(saved*n, dtype=np.complex128)] + [flat[k].astype(np.complex128) for k in ABSORPTION_INPUTS]
+
+
+def test_weak_damping_on_the_oracle_matches_the_reference_graph_layer():
+    """absorption::weak_damping (absorption.hpp:346-432; cold_plasma_expansion, hot_plasma_expansion<z_erfi>,
+    EFIT; complex<double>, SAFE_MATH) along 8 rays of the CLI beam through the cyclotron resonance.
+    Golden: the reference graph layer's DAG evaluated in the host's std::complex arithmetic with the
+    reference's own special::erfi (tests/golden/make_absorption_golden.py).  The oracle evaluates the
+    same DAG with the arithmetic the device is specified in (textbook product, Smith's quotient,
+    Weideman erfi); no reference fixture fixes complex kernels to the bit, so the two are held to
+    1e-13 relative in EACH part — including imaginary parts down to 1e-303, which exist only because
+    erfi of a real argument is real on both sides (special_functions.hpp:1499-1504)."""
+    golden = np.load(os.path.join(GOLDEN, "absorption_golden.npz"))
+    item = gfir.Item(os.path.join(WORKLOADS, "weak_damping_kimg_kernel_c64.gfir"))
+    columns = absorption_columns(golden["records"])
+    item.run(columns, steps=1)
+    got, want = columns[0], golden["kamp"].reshape(-1)
+    assert np.isfinite(want.real).all() and np.isfinite(want.imag).all()
+    assert (want.imag > 1.0).any() and (want.imag == 0.0).any()           # damping where the resonance is, none outside the plasma
+    assert np.array_equal(got.imag == 0.0, want.imag == 0.0)
+    np.testing.assert_allclose(got.real, want.real, rtol=1.0e-13, atol=0.0)
+    np.testing.assert_allclose(got.imag, want.imag, rtol=1.0e-13, atol=0.0)
+
+
+def test_power_item_on_the_oracle_matches_the_reference_bit_for_bit():
+    """bin_power's `power` item (graph_driver/xrays.cpp:706-741) over the golden records: real
+    arithmetic, so bit for bit."""
+    golden = np.load(os.path.join(GOLDEN, "absorption_golden.npz"))
+    records, kamp, power = golden["records"], golden["kamp"], golden["power"]
+    item = gfir.Item(os.path.join(WORKLOADS, "power_f64.gfir"))
+    n = records.shape[2]
+    first = [records[0, 2].copy(), records[0, 3].copy(), records[0, 4].copy()]
+    columns = [c.copy() for c in first] + first + [np.zeros(n), np.ones(n), np.zeros(n)]
+    for r in range(1, records.shape[0]):
+        for c in range(3):
+            columns[c] = records[r, 2 + c].copy()
+        columns[6] = kamp[r].imag.copy()
+        outs, _ = item.run(columns, steps=1)
+        assert np.array_equal(columns[7], power[r - 1, 0]) and np.array_equal(outs[0], power[r - 1, 1])
+        assert np.array_equal(columns[8], power[r - 1, 2])
+    assert 0.0 < power[-1, 0].min() and power[-1, 0].max() < 0.5           # the beam is absorbed
