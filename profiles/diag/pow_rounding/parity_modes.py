@@ -1,7 +1,7 @@
 import os, sys, subprocess
 import numpy as np
 here = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.join(here, ".."))
+sys.path.insert(0, os.path.join(here, "..", "..", ".."))
 STATE = ("t", "w", "x", "y", "z", "kx", "ky", "kz")
 if len(sys.argv) > 1:
     from graph_framework_amd.xrays import Rk4ColdPlasmaEfit, workload

@@ -1,7 +1,7 @@
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "..", "tests"))
 from graph_framework_amd.xrays import Rk4ColdPlasmaEfit, cli_distribution, workload
 from oracle import gfir
 STATE = ("t", "w", "x", "y", "z", "kx", "ky", "kz")
@@ -46,5 +46,5 @@ for s in range(10):
     print("step", s, "residual oracle", outs[0], "device", res, "flags", solve2.work.context.flags())
     if any(((h[k] != e) & ~(np.isnan(h[k]) & np.isnan(e))).any() for k, e in zip(STATE, sub)):
         print("state before:", {k: [float.hex(float(v)) for v in b] for k, b in zip(STATE, before)})
-        np.save(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out", "parity_before.npy"), np.stack(before))
+        np.save(os.path.join(os.path.dirname(os.path.abspath(__file__)), "parity_before.npy"), np.stack(before))
         break

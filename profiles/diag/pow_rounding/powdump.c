@@ -3,7 +3,7 @@
 #include <stdlib.h>
 static double my_pow(double a, double b) { double r = pow(a, b); fprintf(stderr, "%a %a %a\n", a, b, r); return r; }
 #define pow my_pow
-#include "../oracle/gfir_interp.c"
+#include "../../../oracle/gfir_interp.c"
 int main(int argc, char **argv) {
     FILE *f = fopen(argv[1], "rb"); fseek(f, 0, SEEK_END); long n = ftell(f); rewind(f);
     uint8_t *d = malloc(n); fread(d, 1, n, f); fclose(f);
