@@ -87,13 +87,42 @@ class WeakDamping:
         self.work.context.close()
 
 
-def run_absorption(filename, num_steps, index=0):
-    """run_absorption<weak_damping> (xrays.cpp:551-585): records 0 .. num_steps."""
-    power = WeakDamping(filename, index)
+class RootFinder(WeakDamping):
+    """absorption::root_finder<std::complex<double>, true> (absorption.hpp:119-290): per stored record
+    kamp <- 0 (`root_find_init_kernel`), Newton on the hot-plasma D(k + kamp k_hat) for the complex kamp
+    (the converge item `loss_kernel` of solver::newton, newton.hpp:34-51: tolerance 1e-30, at most 1000
+    iterations, the max over the shard is the element of largest modulus), kamp <- |k| + kamp
+    (`final_kamp`)."""
+
+    def __init__(self, filename, index=0, stream=None, items=None, tolerance=1.0e-30, max_iterations=1000):
+        items = items or {}
+        self.file = ResultFile(filename)
+        self.num_rays = self.file.num_rays
+        self.work = Manager(index, stream)
+        zeros = np.zeros(self.num_rays, dtype=np.complex128)
+        self.host = {name: zeros.copy() for name in WEAK_DAMPING_INPUTS}
+        first = WEAK_DAMPING_INPUTS[:7]                                    # kamp kx ky kz x y z, absorption.hpp:170-178
+        self.work.add_item(items.get("init") or workload("root_find_init_kernel", "c64"), first, [], self.num_rays, self.host)
+        self.newton = self.work.add_converge_item(items.get("loss") or workload("root_find_loss_kernel", "c64"),
+                                                  WEAK_DAMPING_INPUTS, ["root_find_residual"], self.num_rays, self.host,
+                                                  tolerance, max_iterations)
+        self.work.add_item(items.get("final") or workload("root_find_final_kamp", "c64"), first, [], self.num_rays, self.host)
+        self.iterations = []
+        self.sync = _Writer()
+
+    def run(self, time_index):
+        super().run(time_index)
+        self.iterations.append(self.newton.iterations)
+
+
+def run_absorption(filename, num_steps, index=0, model="weak_damping"):
+    """run_absorption<ABSORPTION_MODEL> (xrays.cpp:551-585, model chosen as :634-651): records 0 .. num_steps."""
+    power = (RootFinder if model == "root_find" else WeakDamping)(filename, index)
     power.compile()
     for j in range(num_steps + 1):
         power.run(j)
     power.close()
+    return power
 
 
 def bin_power(filename, num_steps, index=0, stream=None, item=None):

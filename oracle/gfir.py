@@ -147,6 +147,9 @@ class Item:
         def max_kernel():
             outs, _ = self.run(columns)
             values = outs[-1]
+            if np.iscomplexobj(values):
+#  complex items: the element of largest modulus, the first of equals (cpu_context.hpp:314-318)
+                return complex(values[int(np.argmax(np.abs(values)))]), outs
 #  std::max_element (cpu_context.hpp:306-322): `m < x` is false for NaN, so a NaN is never
 #  selected unless it is the first element.
             if np.isnan(values[0]):
@@ -156,6 +159,8 @@ class Item:
         big = float(np.finfo(self.np_dtype).max)
         iterations = 0
         max_residual, outs = max_kernel()
+        if isinstance(max_residual, complex):
+            big = 0.0j                               # std::numeric_limits<std::complex<T>>::max() is T()
         last_max = big
         off_last_max = big
         while (abs(max_residual) > abs(tolerance) and abs(last_max - max_residual) > abs(tolerance)

@@ -884,6 +884,90 @@ leaf<T, S> hot_plasma_expansion_D(leaf<T, S> w, vec3<T, S> k_vec, leaf<T, S> x, 
            (gamma1 + gamma2 + nperp2/(2.0*npara)*(w*w/(ec*ec))*vtnorm*zeta*gamma5)*(1.0/Z_func + zeta);
 }
 
+//  dispersion::hot_plasma<T, z_erfi, SAFE_MATH>::D, dispersion.hpp:1106-1163.
+template<typename T, bool S>
+leaf<T, S> hot_plasma_D(leaf<T, S> w, vec3<T, S> k_vec, leaf<T, S> x, leaf<T, S> y, leaf<T, S> z,
+                        equilibrium_base<T, S> &eq) {
+    const absorption_constants<T> p;
+    auto b_vec = eq.get_magnetic_field(x, y, z);
+    auto b_len = b_vec->length();
+    auto b_hat = b_vec/b_len;
+    auto ne = eq.get_electron_density(x, y, z);
+    auto te = eq.get_electron_temperature(x, y, z);
+
+    auto ve = graph::sqrt(static_cast<T> (2.0)*p.q*te/p.me)/p.c;
+
+    auto ec = p.q*b_len/(p.me*p.c);
+    auto wpe2 = ne*p.q*p.q/(p.epsilon0*p.me*p.c*p.c);
+
+    auto P = wpe2/(w*w);
+    auto q = P/(2.0*(1.0 + ec/w));
+
+    auto n = k_vec/w;
+    auto n2 = n->dot(n);
+    auto npara = n->dot(b_hat);
+    auto npara2 = npara*npara;
+    auto nperp = b_hat->cross(n);
+    auto nperp2 = nperp->dot(nperp);
+
+    auto zeta = (1.0 - ec/w)/(npara*ve);
+    auto Z_func = z_erfi_Z<T, S> (zeta);
+    auto zeta_func = 1.0 + zeta*Z_func;
+    auto F = ve*zeta*w/(2.0*npara*ec);
+    auto isigma = P*Z_func/(2.0*npara*ve);
+
+    auto q_func = 1.0 - 2.0*q;
+    auto n_func = n2 + npara2;
+    auto p_func = 1.0 - P;
+
+    auto gamma5 = n2*npara2 - (1.0 - q)*n_func + q_func;
+    auto gamma2 = (n2 - q_func)
+                + P*w/(4.0*ec*npara2)*(n_func - 2.0*q_func);
+    auto gamma1 = nperp2*((1.0 - q)*n2 - q_func)
+                + p_func*(n2*npara2 - (1.0 - q)*n_func + q_func);
+    auto gamma0 = nperp2*(n2 - 2.0*q_func) + p_func*(2.0*q_func - n_func);
+
+    return isigma*gamma0 + gamma1 + nperp2*P*w/ec*zeta_func*(gamma2 + gamma5*F);
+}
+
+//  absorption::root_finder ctor, absorption.hpp:146-226: three items in the order manager::run executes
+//  them — `root_find_init_kernel` (kamp <- 0), the converge item `loss_kernel` of solver::newton
+//  (newton.hpp:34-51) on the hot-plasma D(k + kamp k_hat) with kamp the unknown, `final_kamp`
+//  (kamp <- |k| + kamp).
+template<typename T, bool S>
+struct root_finder_items {
+    leaf<T, S> kamp, w, kx, ky, kz, x, y, z, t;
+    std::unique_ptr<work_item<T, S>> init, loss, final_kamp;
+
+    explicit root_finder_items(equilibrium_base<T, S> &eq) {
+        w = graph::variable<T, S> (1, "\\omega");
+        kx = graph::variable<T, S> (1, "k_{x}");
+        ky = graph::variable<T, S> (1, "k_{y}");
+        kz = graph::variable<T, S> (1, "k_{z}");
+        x = graph::variable<T, S> (1, "x");
+        y = graph::variable<T, S> (1, "y");
+        z = graph::variable<T, S> (1, "z");
+        t = graph::variable<T, S> (1, "t");
+        kamp = graph::variable<T, S> (1, "kamp");
+
+        auto kvec = kx*eq.esup(0) + ky*eq.esup(1) + kz*eq.esup(2);
+        auto klen = kvec->length();
+        auto kamp_vec = kamp*kvec/klen;
+
+        std::vector<leaf<T, S>> inputs = {kamp, kx, ky, kz, x, y, z};
+        init.reset(new work_item<T, S> (inputs, {}, {{graph::zero<T, S> (), kamp}}));
+
+        std::vector<leaf<T, S>> newton_inputs = inputs;
+        newton_inputs.push_back(t);
+        newton_inputs.push_back(w);
+        auto D = hot_plasma_D<T, S> (w, kvec + kamp_vec, x, y, z, eq);
+        const T step = 1.0;
+        loss.reset(new work_item<T, S> (newton_inputs, {D*D}, {{kamp - step*D/D->df(kamp), kamp}}));
+
+        final_kamp.reset(new work_item<T, S> (inputs, {}, {{klen + kamp, kamp}}));
+    }
+};
+
 //  absorption::weak_damping ctor, absorption.hpp:346-432: the one work item of the pass,
 //  `weak_damping_kimg_kernel`, inputs {kamp, kx, ky, kz, x, y, z, t, w}, no outputs, one setter
 //      kamp <- |k| - Dw/(k_hat . grad_k Dc).

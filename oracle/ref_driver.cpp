@@ -655,6 +655,61 @@ static int cmd_weak_damping(const raw_tables &raw, const char *in_path, const ch
     return 0;
 }
 
+//  root_finder <in: kamp kx ky kz x y z t w (real columns)> <out: re(kamp) im(kamp) iterations> <gfir dir|->
+//  absorption::root_finder (absorption.hpp:146-290) on complex<double>, SAFE_MATH = true: init, the Newton
+//  converge item on the whole batch as one shard (workflow.hpp:179-205 with T complex: the max is the element
+//  of largest modulus, cpu_context.hpp:314-318; numeric_limits<std::complex>::max() is T()), final_kamp.
+static int cmd_root_finder(const raw_tables &raw, const char *in_path, const char *out_path, const char *gfir_dir) {
+    typedef std::complex<double> T;
+    size_t n;
+    auto cols = read_columns(in_path, 9, n);
+    efit<T, true> eq(raw);
+    root_finder_items<T, true> items(eq);
+    items.loss->code.print_counts(stderr);
+    if (std::string(gfir_dir) != "-") {
+        const std::string dir(gfir_dir);
+        items.init->write_gfir("root_find_init_kernel", dir + "/root_find_init_kernel_c64.gfir");
+        items.loss->write_gfir("loss_kernel", dir + "/root_find_loss_kernel_c64.gfir");
+        items.final_kamp->write_gfir("final_kamp", dir + "/root_find_final_kamp_c64.gfir");
+    }
+    std::vector<std::vector<T>> columns;
+    for (auto &c : cols) columns.emplace_back(c.begin(), c.end());
+    items.init->run(n, pointers(columns, 0, 7), {});
+    std::vector<T> residual(n);
+    auto max_kernel = [&] () -> T {
+        items.loss->run(n, pointers(columns, 0, 9), {residual.data()});
+        return *std::max_element(residual.begin(), residual.end(),
+                                 [] (const T a, const T b) { return std::abs(a) < std::abs(b); });
+    };
+    const T tolerance = 1.0E-30;
+    const size_t max_iterations = 1000;
+    size_t iterations = 0;
+    T max_residual = max_kernel();
+    T last_max = std::numeric_limits<T>::max();
+    T off_last_max = std::numeric_limits<T>::max();
+    while (std::abs(max_residual) > std::abs(tolerance)                &&
+           std::abs(last_max - max_residual) > std::abs(tolerance)     &&
+           std::abs(off_last_max - max_residual) > std::abs(tolerance) &&
+           iterations++ < max_iterations) {
+        last_max = max_residual;
+        if (!(iterations%2)) {
+            off_last_max = max_residual;
+        }
+        max_residual = max_kernel();
+    }
+    items.final_kamp->run(n, pointers(columns, 0, 7), {});
+    fprintf(stderr, "{\"iterations\": %zu, \"max_residual\": [%.17g, %.17g]}\n", iterations,
+            std::real(max_residual), std::imag(max_residual));
+    std::vector<std::vector<double>> out(3, std::vector<double> (n));
+    for (size_t i = 0; i < n; i++) {
+        out[0][i] = std::real(columns[0][i]);
+        out[1][i] = std::imag(columns[0][i]);
+        out[2][i] = static_cast<double> (iterations);
+    }
+    write_columns(out_path, out);
+    return 0;
+}
+
 //  power <in: x y z x_last y_last z_last kamp power k_sum, then `records` blocks of (x y z kamp)> <out> <records> <gfir|->
 //  bin_power's loop (graph_driver/xrays.cpp:745-775): per record copy x, y, z, kamp in, run the `power`
 //  item once.  out: per record (power, d_power, k_sum).
@@ -746,6 +801,9 @@ int main(int argc, char **argv) {
     if (std::string(argv[2]) == "c64") {
         if (std::string(argv[3]) == "weak_damping" && argc == 7) {
             return cmd_weak_damping(raw, argv[4], argv[5], argv[6]);
+        }
+        if (std::string(argv[3]) == "root_finder" && argc == 7) {
+            return cmd_root_finder(raw, argv[4], argv[5], argv[6]);
         }
         fprintf(stderr, "bad command\n");
         return 2;

@@ -6,6 +6,8 @@ reference's own graph layer (oracle/_ref/gf_ref), and its two work items as GFIR
         absorption.hpp:346-432: complex<double>, SAFE_MATH; cold_plasma_expansion, hot_plasma_expansion
         with z_erfi, EFIT equilibrium)
     graph_framework_amd/workloads/power_f64.gfir                       (bin_power, xrays.cpp:674-790)
+    graph_framework_amd/workloads/root_find_{init_kernel,loss_kernel,final_kamp}_c64.gfir
+        (absorption::root_finder, absorption.hpp:146-290: Newton on the hot-plasma D for the complex kamp)
     tests/golden/absorption_golden.npz
 
 Records: 8 rays of the CLI beam followed with rk4 x ordinary_wave (the documented example, xrays.cpp:
@@ -51,7 +53,18 @@ def main():
         columns += [records[r, 2], records[r, 3], records[r, 4], kamp[r].imag]
     out, _ = R._run("f64", "power", columns, saved - 1, os.path.join(workloads, "power_f64.gfir"))
     power = out.reshape(saved - 1, 3, n)
-    np.savez_compressed(os.path.join(HERE, "absorption_golden.npz"), records=records, kamp=kamp, power=power)
+#  root_finder: every record is one batch (the converge item's max runs over the 8 rays of the record)
+    root, iterations = [], []
+    for r in range(saved):
+        columns = [np.zeros(n)] + [records[r, STATE.index(k)] for k in ("kx", "ky", "kz", "x", "y", "z", "t", "w")]
+        out, info = R._run("c64", "root_finder", columns, workloads if r == 0 else "-")
+        root.append(out[0] + 1j*out[1])
+        iterations.append(int(out[2][0]))
+    root = np.stack(root)
+    np.savez_compressed(os.path.join(HERE, "absorption_golden.npz"), records=records, kamp=kamp, power=power,
+                        root_kamp=root, root_iterations=np.array(iterations))
+    print("root_finder iterations per record", iterations)
+    print("root_finder kamp[6]", root[6, :3])
     print("records", records.shape, "kamp[1]", kamp[1, :3], "power[-1]", power[-1, 0, :3])
     print("finite kamp:", np.isfinite(kamp).all(), " max |Im kamp|", np.abs(kamp.imag).max())
 

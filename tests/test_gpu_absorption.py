@@ -96,3 +96,54 @@ def test_absorption_pass_over_a_trajectory_file(tmp_path):
         np.testing.assert_allclose(d_power[r], outs[0], rtol=1.0e-13, atol=1.0e-15)
     np.testing.assert_allclose(power[1:], golden["power"][:, 0], rtol=1.0e-10, atol=0.0)
     assert 0.0 < power[-1].min() and power[-1].max() < 0.5
+
+
+def _trajectory_file(tmp_path, golden):
+    from graph_framework_amd.output import RAY_VARIABLES, ResultFile
+    records = golden["records"]
+    saved, _, n = records.shape
+    path = str(tmp_path / "result0.nc")
+    trace = ResultFile(path, n)
+    for name, _ in RAY_VARIABLES:
+        trace.create_variable(name)
+    column = {k: i for i, k in enumerate(STATE + ("residual",))}
+    for r in range(saved):
+        trace.write({name: records[r, column[key]] for name, key in RAY_VARIABLES})
+    trace.close()
+    return path
+
+
+def test_root_finder_pass_over_a_trajectory_file(tmp_path):
+    """`--absorption_model=root_find` (xrays.cpp:634-642): absorption::root_finder's three items per
+    stored record — the complex Newton converge item included — against the oracle on the same
+    records and against the reference graph layer's roots (tolerance and what is comparable:
+    tests/test_oracle.py::root_finder_matches)."""
+    from graph_framework_amd.absorption import run_absorption
+    from graph_framework_amd.output import ResultFile
+    from oracle import gfir
+    from test_oracle import ABSORPTION_INPUTS, root_finder_matches
+    golden = np.load(os.path.join(GOLDEN, "absorption_golden.npz"))
+    records = golden["records"]
+    saved, _, n = records.shape
+    path = _trajectory_file(tmp_path, golden)
+    model = run_absorption(path, saved - 1, model="root_find")
+    result = ResultFile(path)
+    kamp = np.stack([result.read("kamp", r) + 1j*result.read("kamp", r, part=1) for r in range(saved)])
+    result.close()
+    assert len(model.iterations) == saved
+    assert root_finder_matches(kamp, golden["root_kamp"], model.iterations, golden["root_iterations"]) >= 15
+
+    init = gfir.Item(os.path.join(WORKLOADS, "root_find_init_kernel_c64.gfir"))
+    loss = gfir.Item(os.path.join(WORKLOADS, "root_find_loss_kernel_c64.gfir"))
+    final = gfir.Item(os.path.join(WORKLOADS, "root_find_final_kamp_c64.gfir"))
+    expected, iterations = [], []
+    for r in range(saved):
+        columns = [np.zeros(n, dtype=np.complex128)] + [records[r, STATE.index(k)].astype(np.complex128) for k in ABSORPTION_INPUTS]
+        init.run(columns[:7])
+        count, _, _ = loss.converge(columns)
+        final.run(columns[:7])
+        expected.append(columns[0].copy())
+        iterations.append(count)
+    assert root_finder_matches(kamp, np.stack(expected), model.iterations, iterations) >= 15
+#  outside the plasma nothing but exact arithmetic is involved: same bits, same iteration counts
+    assert np.array_equal(kamp[:3], np.stack(expected)[:3]) and list(model.iterations[:3]) == iterations[:3]

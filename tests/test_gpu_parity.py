@@ -224,9 +224,11 @@ def test_incoherent_beam_500_steps():
 
     Tolerance, stated: every node but one is bit-exact.  `pow(x, 1.5)` (4 per step) is the host libm's
     on the reference side — glibc's here, accurate to ~0.5002 ulp, i.e. NOT always the correctly
-    rounded value — and the correctly rounded value on the device (tests/test_gpu_pow.py), so about
-    one call in 1e7 differs in its last bit.  Of this beam's 4096 x 500 x 4 calls one does (ray 2472,
-    step 442: x = 0x1.346fd7824e0a9p+2, glibc 0.50017 ulp off).  Hence: per 100-step chunk all but
+    rounded value — and the correctly rounded value on the device (tests/test_gpu_pow.py).  The two
+    differ in the last bit of about 0.4 % of the calls (profiles/r02_fission_experiment.md), but the
+    power enters sums with much larger terms, so the difference reaches the stored state about once
+    in 1e7 calls: of this beam's 4096 x 500 x 4 calls one does (ray 2472, step 442:
+    x = 0x1.346fd7824e0a9p+2, glibc 0.50017 ulp off).  Hence: per 100-step chunk all but
     at most 2 rays are bit-identical; a ray that is not is stepped one step at a time on both sides
     from the same state and every step is held to 1e-9 relative (the north star's bound is 1e-6),
     with at most 2 steps of the 100 not bit-equal; the oracle then follows the device for that ray.

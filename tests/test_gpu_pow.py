@@ -1,8 +1,8 @@
 """pow(x, 1.5) on the device is the correctly rounded value of x^(3/2).
 
 The reference emits `pow(x, 1.5)` and leaves its value to the libm behind the backend (the host's on
-cpu_context, CUDA's on cuda_context): glibc's is accurate to ~0.5002 ulp, i.e. it misses the
-correctly rounded value about once in 1e7 calls.  The lowering computes x*sqrt(x) with the square
+cpu_context, CUDA's on cuda_context): glibc's is accurate to ~0.502 ulp, i.e. it misses the
+correctly rounded value in a fraction of a percent of the calls.  The lowering computes x*sqrt(x) with the square
 root's rounding error carried into the product (graph_framework_amd/csrc/prelude.hpp,
 gf_pow_three_halves) and is held here to the exact value, rounded once — computed with integer
 arithmetic below — on random arguments over the plasma terms' range and beyond, and on the one

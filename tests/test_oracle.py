@@ -339,3 +339,44 @@ def test_power_item_on_the_oracle_matches_the_reference_bit_for_bit():
         assert np.array_equal(columns[7], power[r - 1, 0]) and np.array_equal(outs[0], power[r - 1, 1])
         assert np.array_equal(columns[8], power[r - 1, 2])
     assert 0.0 < power[-1, 0].min() and power[-1, 0].max() < 0.5           # the beam is absorbed
+
+
+def root_finder_matches(got, want, iterations_got, iterations_want):
+    """absorption::root_finder against another arithmetic (std::complex on the host, the device's libm):
+    the Newton loop stops on stagnation at 1e-30, so iteration counts and the noise below 1e-12 |kamp|
+    (imaginary parts of 1e-100 next to a real part of 200) are not comparable; the root is.  Records on
+    which either side runs out of iterations, or the reference graph itself ends in NaN, are skipped."""
+    compared = 0
+    for r in range(want.shape[0]):
+        if iterations_got[r] > 1000 or iterations_want[r] > 1000 or not np.isfinite(want[r]).all():
+            continue
+        assert np.isfinite(got[r]).all(), r
+        assert (np.abs(got[r] - want[r]) <= 1.0e-12*np.abs(want[r])).all(), (r, got[r], want[r])
+        compared += 1
+    return compared
+
+
+def test_root_finder_on_the_oracle_finds_the_reference_roots():
+    """absorption::root_finder (absorption.hpp:146-290): init, Newton converge item on the hot-plasma
+    dispersion function for the complex kamp, final_kamp — per stored record of the golden
+    trajectories, against the reference graph layer evaluated in std::complex arithmetic."""
+    golden = np.load(os.path.join(GOLDEN, "absorption_golden.npz"))
+    records, want, iterations_want = golden["records"], golden["root_kamp"], golden["root_iterations"]
+    init = gfir.Item(os.path.join(WORKLOADS, "root_find_init_kernel_c64.gfir"))
+    loss = gfir.Item(os.path.join(WORKLOADS, "root_find_loss_kernel_c64.gfir"))
+    final = gfir.Item(os.path.join(WORKLOADS, "root_find_final_kamp_c64.gfir"))
+    got, iterations = [], []
+    for r in range(records.shape[0]):
+        columns = [np.full(records.shape[2], 5.0 + 1.0j)] + \
+                  [records[r, STATE.index(k)].astype(np.complex128) for k in ABSORPTION_INPUTS]
+        init.run(columns[:7])
+        assert (columns[0] == 0.0).all()
+        count, _, _ = loss.converge(columns)
+        final.run(columns[:7])
+        got.append(columns[0].copy())
+        iterations.append(count)
+    assert root_finder_matches(np.stack(got), want, iterations, iterations_want) >= 15
+#  the first records lie outside the plasma: no damping, and there the two arithmetics agree to the bit
+    assert np.array_equal(np.stack(got)[:3], want[:3]) and iterations[:3] == list(iterations_want[:3])
+#  where the wave is damped the two models agree on Im k within 15 % (record 6: the resonance)
+    assert np.allclose(want[6].imag, golden["kamp"][6].imag, rtol=0.15)
