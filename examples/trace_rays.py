@@ -4,10 +4,13 @@ graph_driver/xrays.cpp:419-461 (per device: initial distribution, Newton solve f
 with a record every `sub_steps`, result<rank>.nc) on the MI355X backend.
 
     python examples/trace_rays.py --rays 100000 --steps 1000 --sub-steps 100 [--output /tmp/rays]
+    python examples/trace_rays.py --rays 10000 --steps 2000 --sub-steps 100 --output /tmp/rays --absorption-model weak_damping
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/trace_rays.py ...
 
 One process per GPU; the ensemble is split as the reference splits it over device threads; every rank
 writes its own file (as the reference does).  The exported work items fix dt = 1e-3.
+With --absorption-model the two stages that follow the trace in graph_driver/xrays.cpp:1100-1105 run on
+the same file: calculate_power (kamp per stored record) and bin_power (power, d_power).
 """
 import argparse
 import os
@@ -24,6 +27,8 @@ def main():
     parser.add_argument("--steps", type=int, default=1000)
     parser.add_argument("--sub-steps", type=int, default=100, help="steps between trajectory records")
     parser.add_argument("--output", default=None, help="prefix of the result files (default: no output)")
+    parser.add_argument("--absorption-model", choices=["weak_damping", "root_find"], default=None,
+                        help="after the trace: kamp and power into the result file (needs --output)")
     args = parser.parse_args()
 
     import torch
@@ -57,6 +62,21 @@ def main():
           % (rank, end - begin, solve.newton_iterations, residual, args.steps, elapsed,
              (end - begin)*args.steps/elapsed, np.nanmin(host["x"]), np.nanmax(host["x"]), lost,
              solve.work.context.flags()))
+    if writer and args.absorption_model:
+        from graph_framework_amd.absorption import bin_power, run_absorption
+        from graph_framework_amd.output import ResultFile
+        solve.work.context.close()
+        path = "%s%d.nc" % (args.output, rank)
+        records = args.steps//args.sub_steps
+        start = time.perf_counter()
+        run_absorption(path, records, index=local_rank, model=args.absorption_model)
+        bin_power(path, records, index=local_rank)
+        elapsed = time.perf_counter() - start
+        result = ResultFile(path)
+        power = result.read("power", records)
+        result.close()
+        print("rank %d: absorption (%s) + power over %d records in %.3f s; transmitted power of the beam %.4f"
+              % (rank, args.absorption_model, records + 1, elapsed, float(np.nanmean(power))))
 
 
 if __name__ == "__main__":
