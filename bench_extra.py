@@ -187,6 +187,39 @@ def trajectory(n=1000000, steps=400, every=100):
                     "only if a record takes longer to write than `every` steps take to compute"}
 
 
+def absorption(n=1000000, steps=20):
+    """The absorption pass's kernel (absorption::weak_damping, complex<double> + SAFE_MATH + erfi) on n rays
+    spread over the golden trajectories' records (inside, at and outside the resonance).  Algorithmic bytes
+    per ray: 9 complex inputs read + kamp written = 160 B."""
+    from graph_framework_amd import Context
+    from graph_framework_amd.xrays import workload
+    golden = np.load(os.path.join(ROOT, "tests", "golden", "absorption_golden.npz"))
+    records = golden["records"]
+    flat = {k: records[:, i, :].reshape(-1) for i, k in enumerate(("t", "w", "x", "y", "z", "kx", "ky", "kz"))}
+    pick = np.random.default_rng(0).integers(0, flat["t"].size, n)
+    keys = ("kamp", "kx", "ky", "kz", "x", "y", "z", "t", "w")
+    columns = [np.zeros(n, dtype=np.complex128)] + [flat[k][pick].astype(np.complex128) for k in keys[1:]]
+    context = Context(0)
+    kernel = context.add_kernel(workload("weak_damping_kimg_kernel", "c64"), n)
+    context.compile()
+    kernel.create_kernel_call(keys, [], columns)
+    kernel.run(1)
+    context.enable_timing(True)
+    context.wait()
+    start = time.perf_counter()
+    for _ in range(steps):
+        kernel.run(1)
+    context.wait()
+    elapsed = time.perf_counter() - start
+    ms, launches = kernel.timing()
+    info = kernel.info()
+    achieved = n*160/(ms*1.0e-3)/1.0e9
+    return {"workload": "weak_damping_kimg_kernel, %d rays, complex<double> SAFE_MATH" % n, "value": n*steps/elapsed,
+            "unit": "rays/s", "kernel_ms": ms, "launches": int(launches), "vgprs": info.vgprs, "nodes": info.num_instructions,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved/8000.0,
+                         "note": "160 B per ray; 423 complex nodes with one erfi: arithmetic bound"}}
+
+
 def fused(n=1000000, steps=200, per_launch=10):
     """RK4 with `per_launch` steps fused into one launch (xrays_bench's SUB_STEPS = 10)."""
     from graph_framework_amd.xrays import Rk4ColdPlasmaEfit
@@ -222,6 +255,8 @@ if __name__ == "__main__":
         out = trajectory()
     elif what == "fused":
         out = fused()
+    elif what == "absorption":
+        out = absorption()
     else:
         raise SystemExit("unknown workload")
     print(json.dumps(out))

@@ -6,6 +6,7 @@
 set -o pipefail
 R=$(pwd)
 OUT=$R/gpurun_out/r02
+rm -rf $OUT
 mkdir -p $OUT
 python3 $R/bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err || exit 1
 python3 $R/bench.py --rays-per-gpu 1000000 --no-extra --no-cpu-baseline > $OUT/bench_n1_1e6.json 2>> $OUT/bench_n1.err || exit 1
@@ -32,7 +33,7 @@ for item in korc_f32 korc_f64 loss; do
     done
 done
 cd $R
-for item in korc_f32 korc_f64 loss loss_per_ray fused solver_f32 stream_f32 stream_f64 stream7_f32 stream7_f64 trajectory; do
+for item in korc_f32 korc_f64 loss loss_per_ray fused solver_f32 stream_f32 stream_f64 stream7_f32 stream7_f64 trajectory absorption; do
     python3 $R/bench_extra.py $item >> $OUT/extra_items.jsonl 2>> $OUT/extra.err || echo "extra failed: $item" >> $OUT/failed.txt
 done
 $R/graph_framework_amd/xrays_bench $R/graph_framework_amd/workloads 10000000 1000 > $OUT/xrays_bench_cpp.log 2>&1

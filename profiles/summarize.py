@@ -3,6 +3,10 @@
 
     python profiles/summarize.py pmc <dir> [kernel-substring]     mean of every counter per kernel
     python profiles/summarize.py stats <dir>                      the kernel rows of *_kernel_stats.csv
+    python profiles/summarize.py traffic <bench.json> <traffic.json> <kernel>=<FETCH_SIZE dir>,<WRITE_SIZE dir> ...
+        HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB counters; the factor 2 is gfx950's,
+        MI355X_MICROARCH.md "HBM"), keyed by the code object's source hash and launch size taken from the
+        bench line, which is what bench.py's roofline.traffic looks up.
 """
 import csv
 import glob
@@ -37,9 +41,46 @@ def stats(directory):
     return rows
 
 
+def traffic(bench_path, out_path, specs):
+    import json
+    with open(bench_path) as f:
+        line = json.loads([l for l in f if l.startswith("{")][-1])
+    rooflines = {line["roofline"]["kernel"]: dict(line["roofline"], units_per_launch=line["config"]["rays_per_gpu"])}
+    for extra in line.get("roofline_extra", {}).values():
+        rooflines[extra["kernel"]] = extra
+    entries = []
+    for spec in specs:
+        kernel, directories = spec.split("=")
+        fetch_dir, write_dir = directories.split(",")
+
+        def mean(directory, counter):
+            total, count = 0.0, 0
+            for name, counters in pmc(directory).items():
+                if name.startswith(kernel) and counter in counters:
+                    total += counters[counter][0]*counters[counter][1]
+                    count += counters[counter][1]
+            return total/count, count
+
+        fetch, launches = mean(fetch_dir, "FETCH_SIZE")
+        write, _ = mean(write_dir, "WRITE_SIZE")
+        roof = rooflines[kernel]
+        entries.append({"kernel": kernel, "source_hash": roof["source_hash"], "rays_per_launch": roof["units_per_launch"],
+                        "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write, "fetch_correction": 2.0,
+                        "traffic_bytes_per_launch": (2.0*fetch + write)*1024.0,
+                        "algorithmic_bytes_per_launch": roof["algorithmic_bytes_per_launch"], "launches_averaged": launches,
+                        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes (profiles/collect_r02.sh), one MI355X"})
+    with open(out_path, "w") as f:
+        json.dump(entries, f, indent=1)
+    for e in entries:
+        print(e["kernel"], e["source_hash"], e["rays_per_launch"], "traffic %.4g B" % e["traffic_bytes_per_launch"],
+              "algorithmic %.4g B" % e["algorithmic_bytes_per_launch"])
+
+
 if __name__ == "__main__":
     what, directory = sys.argv[1], sys.argv[2]
-    if what == "pmc":
+    if what == "traffic":
+        traffic(sys.argv[2], sys.argv[3], sys.argv[4:])
+    elif what == "pmc":
         for kernel, counters in pmc(directory, sys.argv[3] if len(sys.argv) > 3 else None).items():
             for name, (mean, n) in sorted(counters.items()):
                 print("%s,%s,%.6g,%d" % (kernel[:60], name, mean, n))
