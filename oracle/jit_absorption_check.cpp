@@ -1,0 +1,160 @@
+// ---------------------------------------------------------------------------
+// jit_absorption_check.cpp — TEST INFRASTRUCTURE (oracle/Makefile target _ref/jit_absorption_check;
+// runs on a GPU box, tests/test_gpu_workflows.py).
+//
+// The absorption pass's work items under the reference's REAL workflow::manager, jit::context and
+// solver::newton (workflow.hpp, jit.hpp, newton.hpp compiled where they lie with -DUSE_HIP), i.e. what
+// absorption::weak_damping / root_finder do with their graphs (absorption.hpp:146-226, :346-432) minus
+// the NetCDF file (output.hpp needs netcdf.h, which the image lacks): complex<double>, SAFE_MATH = true,
+// erfi nodes, and a converge item whose max is a complex number.  The graphs are the restated builders
+// of ref_builders.hpp; the values are checked against the tape (std::complex arithmetic, the reference's
+// special::erfi) with the tolerances of tests/test_oracle.py.
+//
+//   jit_absorption_check <tables.bin> <in: kamp kx ky kz x y z t w (real columns)>
+// ---------------------------------------------------------------------------
+#include <complex>
+
+#include "workflow.hpp"
+#include "newton.hpp"
+
+#include "ref_builders.hpp"
+
+typedef std::complex<double> T;
+constexpr bool S = true;
+
+static std::vector<std::vector<double>> read_columns(const char *path, const size_t cols, size_t &n) {
+    FILE *f = fopen(path, "rb");
+    if (!f) { perror(path); exit(1); }
+    uint64_t n64;
+    if (fread(&n64, 8, 1, f) != 1) { fprintf(stderr, "short read\n"); exit(1); }
+    n = n64;
+    std::vector<std::vector<double>> out(cols, std::vector<double> (n));
+    for (auto &c : out) {
+        if (fread(c.data(), 8, n, f) != n) { fprintf(stderr, "short read\n"); exit(1); }
+    }
+    fclose(f);
+    return out;
+}
+
+template<typename ITEMS>
+static void load(ITEMS &items, const std::vector<std::vector<double>> &cols) {
+    const leaf<T, S> order[9] = {items.kamp, items.kx, items.ky, items.kz, items.x, items.y, items.z, items.t, items.w};
+    for (size_t c = 0; c < 9; c++) {
+        graph::variable_cast(order[c])->set(std::vector<T> (cols[c].begin(), cols[c].end()));
+    }
+}
+
+int main(int argc, char **argv) {
+    if (argc != 3) {
+        fprintf(stderr, "usage: jit_absorption_check <tables.bin> <in>\n");
+        return 2;
+    }
+    const raw_tables raw(argv[1]);
+    size_t n;
+    const auto cols = read_columns(argv[2], 9, n);
+    int failures = 0;
+
+//  weak_damping: one item, one setter (absorption.hpp:411-432).
+    {
+        efit<T, S> eq(raw);
+        weak_damping_item<T, S> item(eq, n);
+        load(item, cols);
+        workflow::manager<T, S> work(0);
+        work.add_item(item.inputs, {}, item.setters, graph::shared_random_state<T, S> (),
+                      "weak_damping_kimg_kernel", n);
+        work.compile();
+        work.run();
+        work.wait();
+        std::vector<T> got(n);
+        work.copy_to_host(item.kamp, got.data());
+
+        std::vector<leaf<T, S>> in(item.inputs.begin(), item.inputs.end());
+        work_item<T, S> tape(in, {}, {{item.kamp1, item.kamp}});
+        std::vector<std::vector<T>> columns;
+        for (auto &c : cols) columns.emplace_back(c.begin(), c.end());
+        std::vector<T *> pointers;
+        for (auto &c : columns) pointers.push_back(c.data());
+        tape.run(n, pointers, {});
+        double worst_re = 0.0, worst_im = 0.0;
+        for (size_t i = 0; i < n; i++) {
+            const T want = columns[0][i];
+            worst_re = std::max(worst_re, std::abs(std::real(got[i]) - std::real(want))/std::abs(std::real(want)));
+            if (std::imag(want) != 0.0) {
+                worst_im = std::max(worst_im, std::abs(std::imag(got[i]) - std::imag(want))/std::abs(std::imag(want)));
+            } else if (std::imag(got[i]) != 0.0) {
+                worst_im = 1.0;
+            }
+        }
+        const bool ok = worst_re <= 1.0e-12 && worst_im <= 1.0e-12;
+        printf("weak_damping over workflow::manager<complex<double>, true>: %zu rays, worst relative difference "
+               "re %.3g im %.3g: %s\n", n, worst_re, worst_im, ok ? "ok" : "FAILED");
+        failures += !ok;
+    }
+
+//  root_finder: init item, solver::newton's converge item, final item (absorption.hpp:166-226).
+    {
+        efit<T, S> eq(raw);
+        root_finder_items<T, S> items(eq, n);
+        load(items, cols);
+        workflow::manager<T, S> work(0);
+        graph::input_nodes<T, S> inputs = {graph::variable_cast(items.kamp), graph::variable_cast(items.kx),
+                                           graph::variable_cast(items.ky), graph::variable_cast(items.kz),
+                                           graph::variable_cast(items.x), graph::variable_cast(items.y),
+                                           graph::variable_cast(items.z)};
+        work.add_item(inputs, {}, {{graph::zero<T, S> (), graph::variable_cast(items.kamp)}}, NULL,
+                      "root_find_init_kernel", n);
+        graph::input_nodes<T, S> newton_inputs = inputs;
+        newton_inputs.push_back(graph::variable_cast(items.t));
+        newton_inputs.push_back(graph::variable_cast(items.w));
+        solver::newton(work, {items.kamp}, newton_inputs, items.D, graph::shared_random_state<T, S> ());
+        work.add_item(inputs, {}, {{items.klen + items.kamp, graph::variable_cast(items.kamp)}}, NULL,
+                      "final_kamp", n);
+        work.compile();
+        work.run();
+        work.wait();
+        std::vector<T> got(n);
+        work.copy_to_host(items.kamp, got.data());
+
+        std::vector<std::vector<T>> columns;
+        for (auto &c : cols) columns.emplace_back(c.begin(), c.end());
+        std::vector<T *> seven, nine;
+        for (size_t c = 0; c < 9; c++) {
+            if (c < 7) seven.push_back(columns[c].data());
+            nine.push_back(columns[c].data());
+        }
+        items.init->run(n, seven, {});
+        std::vector<T> residual(n);
+        auto max_kernel = [&] () -> T {
+            items.loss->run(n, nine, {residual.data()});
+            return *std::max_element(residual.begin(), residual.end(),
+                                     [] (const T a, const T b) { return std::abs(a) < std::abs(b); });
+        };
+        const T tolerance = 1.0E-30;
+        size_t iterations = 0;
+        T max_residual = max_kernel();
+        T last_max = std::numeric_limits<T>::max();
+        T off_last_max = std::numeric_limits<T>::max();
+        while (std::abs(max_residual) > std::abs(tolerance)                &&
+               std::abs(last_max - max_residual) > std::abs(tolerance)     &&
+               std::abs(off_last_max - max_residual) > std::abs(tolerance) &&
+               iterations++ < 1000) {
+            last_max = max_residual;
+            if (!(iterations%2)) {
+                off_last_max = max_residual;
+            }
+            max_residual = max_kernel();
+        }
+        items.final_kamp->run(n, seven, {});
+        double worst = 0.0;
+        for (size_t i = 0; i < n; i++) {
+            worst = std::max(worst, std::abs(got[i] - columns[0][i])/std::abs(columns[0][i]));
+        }
+        const bool converged = iterations <= 1000;
+        const bool ok = !converged || worst <= 1.0e-12;
+        printf("root_finder over workflow::manager + solver::newton: %zu rays, tape %zu iterations%s, worst "
+               "|difference|/|kamp| %.3g: %s\n", n, iterations, converged ? "" : " (not converged: not compared)",
+               worst, ok ? "ok" : "FAILED");
+        failures += !ok;
+    }
+    return failures ? 1 : 0;
+}

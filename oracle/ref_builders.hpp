@@ -939,19 +939,21 @@ struct root_finder_items {
     leaf<T, S> kamp, w, kx, ky, kz, x, y, z, t;
     std::unique_ptr<work_item<T, S>> init, loss, final_kamp;
 
-    explicit root_finder_items(equilibrium_base<T, S> &eq) {
-        w = graph::variable<T, S> (1, "\\omega");
-        kx = graph::variable<T, S> (1, "k_{x}");
-        ky = graph::variable<T, S> (1, "k_{y}");
-        kz = graph::variable<T, S> (1, "k_{z}");
-        x = graph::variable<T, S> (1, "x");
-        y = graph::variable<T, S> (1, "y");
-        z = graph::variable<T, S> (1, "z");
-        t = graph::variable<T, S> (1, "t");
-        kamp = graph::variable<T, S> (1, "kamp");
+    leaf<T, S> D, klen;
+
+    explicit root_finder_items(equilibrium_base<T, S> &eq, const size_t size = 1) {
+        w = graph::variable<T, S> (size, "\\omega");
+        kx = graph::variable<T, S> (size, "k_{x}");
+        ky = graph::variable<T, S> (size, "k_{y}");
+        kz = graph::variable<T, S> (size, "k_{z}");
+        x = graph::variable<T, S> (size, "x");
+        y = graph::variable<T, S> (size, "y");
+        z = graph::variable<T, S> (size, "z");
+        t = graph::variable<T, S> (size, "t");
+        kamp = graph::variable<T, S> (size, "kamp");
 
         auto kvec = kx*eq.esup(0) + ky*eq.esup(1) + kz*eq.esup(2);
-        auto klen = kvec->length();
+        klen = kvec->length();
         auto kamp_vec = kamp*kvec/klen;
 
         std::vector<leaf<T, S>> inputs = {kamp, kx, ky, kz, x, y, z};
@@ -960,7 +962,7 @@ struct root_finder_items {
         std::vector<leaf<T, S>> newton_inputs = inputs;
         newton_inputs.push_back(t);
         newton_inputs.push_back(w);
-        auto D = hot_plasma_D<T, S> (w, kvec + kamp_vec, x, y, z, eq);
+        D = hot_plasma_D<T, S> (w, kvec + kamp_vec, x, y, z, eq);
         const T step = 1.0;
         loss.reset(new work_item<T, S> (newton_inputs, {D*D}, {{kamp - step*D/D->df(kamp), kamp}}));
 
