@@ -3,6 +3,8 @@
 
     python profiles/summarize.py pmc <dir> [kernel-substring]     mean of every counter per kernel
     python profiles/summarize.py stats <dir>                      the kernel rows of *_kernel_stats.csv
+    python profiles/summarize.py round <gpurun_out/rNN> <profiles/rNN>       rNN_kernel_stats.csv + rNN_pmc_summary.csv of every
+                                                                           stats_* / pmc_* directory of a collection
     python profiles/summarize.py traffic <bench.json> <traffic.json> <kernel>=<FETCH_SIZE dir>,<WRITE_SIZE dir> ...
         HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB counters; the factor 2 is gfx950's,
         MI355X_MICROARCH.md "HBM"), keyed by the code object's source hash and launch size taken from the
@@ -54,12 +56,16 @@ def traffic(bench_path, out_path, specs):
         fetch_dir, write_dir = directories.split(",")
 
         def mean(directory, counter):
-            total, count = 0.0, 0
-            for name, counters in pmc(directory).items():
-                if name.startswith(kernel) and counter in counters:
-                    total += counters[counter][0]*counters[counter][1]
-                    count += counters[counter][1]
-            return total/count, count
+#  dispatches that return at once (passes queued behind a converged loop's `stop` word) move no data:
+#  only dispatches with at least half of the largest value count
+            values = []
+            for path in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+                with open(path) as f:
+                    for row in csv.DictReader(f):
+                        if row.get("Kernel_Name", "").startswith(kernel) and row.get("Counter_Name") == counter:
+                            values.append(float(row.get("Counter_Value", 0) or 0))
+            kept = [v for v in values if v >= 0.5*max(values)]
+            return sum(kept)/len(kept), len(kept)
 
         fetch, launches = mean(fetch_dir, "FETCH_SIZE")
         write, _ = mean(write_dir, "WRITE_SIZE")
@@ -76,9 +82,30 @@ def traffic(bench_path, out_path, specs):
               "algorithmic %.4g B" % e["algorithmic_bytes_per_launch"])
 
 
+def whole_round(directory, prefix):
+    with open(prefix + "_kernel_stats.csv", "w") as f:
+        f.write("run,kernel,calls,average_ns,percent\n")
+        for run in sorted(glob.glob(os.path.join(directory, "stats_*"))):
+            if not os.path.isdir(run):
+                continue
+            for row in stats(run):
+                f.write("%s,%s,%s,%s,%s\n" % (os.path.basename(run), row.get("Name", "")[:70].replace(",", ";"), row.get("Calls"),
+                                              row.get("AverageNs"), row.get("Percentage")))
+    with open(prefix + "_pmc_summary.csv", "w") as f:
+        f.write("run,kernel,counter,mean_per_dispatch,samples\n")
+        for run in sorted(glob.glob(os.path.join(directory, "pmc_*"))):
+            if not os.path.isdir(run):
+                continue
+            for kernel, counters in pmc(run).items():
+                for name, (mean, n) in sorted(counters.items()):
+                    f.write("%s,%s,%s,%.6g,%d\n" % (os.path.basename(run), kernel[:50].replace(",", ";"), name, mean, n))
+
+
 if __name__ == "__main__":
     what, directory = sys.argv[1], sys.argv[2]
-    if what == "traffic":
+    if what == "round":
+        whole_round(sys.argv[2], sys.argv[3])
+    elif what == "traffic":
         traffic(sys.argv[2], sys.argv[3], sys.argv[4:])
     elif what == "pmc":
         for kernel, counters in pmc(directory, sys.argv[3] if len(sys.argv) > 3 else None).items():
