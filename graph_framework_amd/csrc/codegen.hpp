@@ -100,7 +100,7 @@ struct kernel_writer {
     const bool cx = it.is_complex();                ///< values are gf_complex (prelude.hpp)
     const bool safe = it.safe_math();               ///< SAFE_MATH guards
     const bool generic = cx || safe || it.has_random();     ///< operations go through the gf_* names
-    const bool track_numerators = opt.division == division_mode::checked;
+    const bool track_numerators = opt.division == division_mode::checked && it.base_is_f64();   // fp32 quotients go through fp64: nothing to track
     const bool fixup = division_fixup(it, opt);
     const char *real = f64 ? "double" : "float";
     const std::string sfx = f64 ? "" : "f";
@@ -154,9 +154,17 @@ struct kernel_writer {
             e << "static_cast<unsigned int> (__builtin_fmin" << sfx << "(__builtin_fmax" << sfx << "(";
             if (shared) {
                 const std::string quotient = "x" + std::to_string(quotient_count++);
-                s << "                const real " << quotient << " = gf_div(" << N(arg) << " - " << literal(offset) << ", " << literal(scale) << ", "
-                  << literal(f64 ? 1.0/scale : static_cast<double> (1.0f/static_cast<float> (scale))) << ");\n";
-                s << "                vmax = __builtin_elementwise_maximum(vmax, gf_magnitude(" << quotient << "));\n";
+                if (f64) {
+                    s << "                const real " << quotient << " = gf_div(" << N(arg) << " - " << literal(offset) << ", " << literal(scale) << ", "
+                      << literal(1.0/scale) << ");\n";
+                    s << "                vmax = __builtin_elementwise_maximum(vmax, gf_magnitude(" << quotient << "));\n";
+                } else {
+//  fp32: the reciprocal is the double nearest to 1/scale (prelude.hpp: quotients through fp64)
+                    char wide[64];
+                    std::snprintf(wide, sizeof(wide), "%a", 1.0/static_cast<double> (static_cast<float> (scale)));
+                    s << "                const real " << quotient << " = gf_div(" << N(arg) << " - " << literal(offset) << ", " << literal(scale) << ", "
+                      << wide << ");\n";
+                }
                 e << quotient;
             } else {
                 const std::string quotient = "(" + N(arg) + " - " + value_literal(offset) + ")/" + value_literal(scale);
@@ -238,7 +246,7 @@ struct kernel_writer {
                     if (shared) {
                         if (!reciprocal_done[c.b]) {
                             reciprocal_done[c.b] = true;
-                            s << ind << "const real q" << c.b << " = gf_rcp(" << N(c.b) << ");\n";
+                            s << ind << (f64 ? "const real q" : "const double q") << c.b << " = gf_rcp(" << N(c.b) << ");\n";
                             s << ind << "dmax = __builtin_elementwise_maximum(dmax, gf_magnitude(" << N(c.b) << "));\n";
                             s << ind << "dmin = __builtin_elementwise_minimum(dmin, gf_magnitude(" << N(c.b) << "));\n";
                         }
@@ -507,25 +515,26 @@ struct kernel_writer {
             s << "            bool bad = false, zero = false;\n";
             s << "            {\n";
             s << "                float dmax = gf_magnitude(" << literal(1.0) << "), dmin = dmax;   // extreme |denominator| of this pass\n";
-            s << "                float vmax = dmax;                                   // extreme |stored value|, |index quotient|\n";
+            if (f64) s << "                float vmax = dmax;                                   // extreme |stored value|, |index quotient|\n";
             if (track_numerators) s << "                unsigned int nmin = 0xFFFFFFFFu;                    // smallest non-zero |numerator| key\n";
             body(true);
 //  The finite checks run on the same fp32 image as the window check (a non-finite value, or a
 //  double of 2^1017 and more, reads as a float NaN/infinity and fails the comparison): half a
 //  v_maximum3_f32 per value.
             std::vector<std::string> quotient_results;
-            for (size_t k = 0; k < it.setters.size(); k++) {
+            for (size_t k = 0; f64 && k < it.setters.size(); k++) {
                 s << "                vmax = __builtin_elementwise_maximum(vmax, gf_magnitude(sv" << k << "));\n";
                 if (after_division[it.setters[k].value]) quotient_results.push_back("sv" + std::to_string(k));
             }
-            for (size_t o = 0; o < it.outputs.size(); o++) {
+            for (size_t o = 0; f64 && o < it.outputs.size(); o++) {
                 s << "                vmax = __builtin_elementwise_maximum(vmax, gf_magnitude(so" << o << "));\n";
                 if (after_division[it.outputs[o]]) quotient_results.push_back("so" + std::to_string(o));
             }
-//  Windows: see the contract at the top of prelude.hpp.
-            const char *low = f64 ? "0x1p-500" : (track_numerators ? "0x1p-60f" : "0x1p-100f");
-            const char *high = f64 ? "0x1p+500" : (track_numerators ? "0x1p+60f" : "0x1p+100f");
-            s << "                bad = !(vmax < __builtin_inff()) || !(dmin >= gf_magnitude(" << low
+//  Windows: see the contract at the top of prelude.hpp.  fp32 (quotients through fp64): every
+//  denominator finite and non-zero, nothing else.
+            const char *low = f64 ? "0x1p-500" : "0x1p-149f";
+            const char *high = f64 ? "0x1p+500" : "0x1.fffffep+127f";
+            s << "                bad = " << (f64 ? "!(vmax < __builtin_inff()) || " : "") << "!(dmin >= gf_magnitude(" << low
               << ")) || !(dmax <= gf_magnitude(" << high << "))";
             if (track_numerators) s << " || nmin < gf_numerator_key(" << (f64 ? "0x1p-450" : "0x1p-60f") << ")";
             s << ";\n";

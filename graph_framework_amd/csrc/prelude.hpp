@@ -4,30 +4,36 @@
 ///  shared-reciprocal division in both precisions, pow(x, 1.5).
 ///
 ///  Division contract.  The reference's cpu_context divides with the compiler's IEEE `/`
-///  (arithmetic.hpp:3508).  hipcc lowers that to: v_div_scale of both operands, r = rcp(d)
-///  refined by Newton steps, q = n*r, residual steps, v_div_fmas (un-scale), v_div_fixup
-///  (special operands).  A work item divides many numerators by few denominators (680
-///  divisions, 82 denominators in the RK4 kernel), so the default mode refines the reciprocal
-///  once per denominator and spends three (fp64) or five (fp32) fused multiply-adds per
-///  quotient — the SAME instructions the compiler's sequence executes when v_div_scale leaves
-///  both operands unscaled, hence the same bits.  The hardware scales when the denominator, its
-///  reciprocal, the quotient or the residual would leave the normal range; every pass therefore
-///  checks, per lane:
-///    * every denominator: finite, non-zero, |d| inside the window (fp64 [2^-500, 2^500],
-///      fp32 [2^-100, 2^100]; `checked` mode fp32 [2^-60, 2^60]);
+///  (arithmetic.hpp:3508).  A work item divides many numerators by few denominators (680
+///  divisions, 82 denominators in the RK4 kernel), so the reciprocal is refined once per
+///  denominator and shared.
+///
+///  fp64.  hipcc lowers `/` to: v_div_scale of both operands, r = rcp(d) refined by Newton steps,
+///  q = n*r, a residual step, v_div_fmas (un-scale), v_div_fixup (special operands).  The default
+///  mode spends three fused multiply-adds per quotient — the SAME instructions the compiler's
+///  sequence executes when v_div_scale leaves both operands unscaled, hence the same bits.  The
+///  hardware scales when the denominator, its reciprocal, the quotient or the residual would leave
+///  the normal range; every pass therefore checks, per lane:
+///    * every denominator: finite, non-zero, |d| inside [2^-500, 2^500];
 ///    * every value the pass stores and every gather argument: finite (an overflowing or
 ///      non-finite numerator turns into a NaN here, where IEEE division gives an infinity);
 ///    * every stored value computed from a quotient: not zero (without v_div_fixup a quotient
 ///      with numerator -0 is +0; a zero keeps its place through every later operation, so it
 ///      can only be seen in a stored zero — or in a division by it, which the first check sees);
-///    * `checked` mode only: every numerator is zero or |n| >= 2^-450 (fp64) / 2^-60 (fp32), so
-///      that neither the residual nor the quotient can be subnormal.
+///    * `checked` mode only: every numerator is zero or |n| >= 2^-450, so that neither the
+///      residual nor the quotient can be subnormal.
+///  What the default mode leaves unchecked in fp64, and `checked` closes at 1.5 vector instructions
+///  per numerator: a non-zero numerator below 2^-969, or a quotient below the normal range, may
+///  differ from IEEE division in the last bit.
+///
+///  fp32 (round 2).  Quotients are rounded from an fp64 product, float(double(n)*r) with r the
+///  refined fp64 reciprocal of d: the IEEE fp32 quotient for EVERY finite n and finite non-zero d,
+///  subnormal and overflowing results and the sign of a zero included (the separation argument is
+///  with gf_div below).  The only check left is that every denominator is finite and non-zero.
+///
 ///  A lane that fails a check REDOES THE PASS with the compiler's division (`<name>_ieee`, a
 ///  function of its own that the hot path never enters on the benchmark workloads) and raises a
-///  status bit (informational; bit 0: window/finite, bit 1: stored zero).
-///  What the default mode leaves unchecked, and `checked` closes at 1.5 vector instructions per
-///  numerator: a non-zero numerator below 2^-969 (fp64) / 2^-102 (fp32), or a quotient below
-///  the normal range, may differ from IEEE division in the last bit.
+///  status bit (informational; bit 0: window/finite, bit 1: stored zero — fp64 only).
 //------------------------------------------------------------------------------
 #ifndef gfhip_prelude_hpp
 #define gfhip_prelude_hpp
@@ -303,22 +309,27 @@ __device__ __forceinline__ unsigned int gf_numerator_key(const double n) {
 }
 )";
     if (!f64) {
-        s << (fixup ? "#define GF_FIXUP(q, d, n) __builtin_amdgcn_div_fixupf(q, d, n)\n"
-                    : "#define GF_FIXUP(q, d, n) (q)\n");
         s << R"(
-// fp32 division as hipcc lowers it (denormals on): r = rcp(d) + one Newton step (shared per
-// denominator), q = n*r refined by two residual steps, a third residual folded in.
-__device__ __forceinline__ float gf_rcp(const float d) {
-    const float r = __builtin_amdgcn_rcpf(d);
-    const float e = __builtin_fmaf(-d, r, 1.0f);
-    return __builtin_fmaf(e, r, r);
+// fp32 quotients through fp64.  The exact quotient n/d of two floats that is not itself a rounding
+// boundary of the fp32 format (a float, or the midpoint of two neighbouring floats: at most 25
+// significant bits M) is at least 1/(M*D) > 2^-49 of its own size away from it (n 2^k - M d is a
+// non-zero integer for 24-bit n, d), subnormal and overflowing results included; a double within
+// 2^-51 of the quotient therefore rounds to the IEEE fp32 quotient, sign of a zero included.
+// r = rcp(d) in fp64 refined by two Newton steps (shared per denominator: 6 instructions),
+// q = float(double(n)*r) (3 per quotient) — 183 -> 156 instructions for the 30 divisions of the
+// xkorc push, and no condition on the numerator, the quotient or a stored zero is left to check:
+// only that every denominator is finite and non-zero (the Newton steps turn rcp(0) = inf and
+// rcp(inf) = 0 into NaN).
+__device__ __forceinline__ double gf_rcp(const float d) {
+    const double wide = d;
+    double r = __builtin_amdgcn_rcp(wide);
+    double e = __builtin_fma(-wide, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-wide, r, 1.0);
+    return __builtin_fma(r, e, r);
 }
-__device__ __forceinline__ float gf_div(const float n, const float d, const float r) {
-    const float q0 = n*r;
-    const float e0 = __builtin_fmaf(-d, q0, n);
-    const float q1 = __builtin_fmaf(e0, r, q0);
-    const float e1 = __builtin_fmaf(-d, q1, n);
-    return GF_FIXUP(__builtin_fmaf(e1, r, q1), d, n);
+__device__ __forceinline__ float gf_div(const float n, const float, const double r) {
+    return static_cast<float> (static_cast<double> (n)*r);
 }
 )";
     }

@@ -6,7 +6,8 @@ lanes whose operands leave the window in which the shared sequence is the IEEE o
 pass with the compiler's division.  Checked here bit for bit against the CPU oracle on operands
 the benchmark never sees: denominators of 2^+-600 (fp64) / 2^+-110 (fp32), zero and infinite
 denominators, zero numerators of either sign, infinite and overflowing numerators, and — in the
-`checked` mode, which also tracks every numerator — subnormal and near-subnormal numerators.
+`checked` mode, which also tracks every numerator, and in fp32, whose quotients are rounded from an
+fp64 product and need no condition on the numerator — subnormal and near-subnormal numerators.
 """
 import numpy as np
 import pytest
@@ -64,7 +65,9 @@ def test_division_at_the_edges_is_the_ieee_quotient(monkeypatch, tmp_path, dtype
     monkeypatch.setenv("GFHIP_CACHE_DIR", str(tmp_path))
     blob = gfir_random.division_stress_item(dtype)
     oracle_item = gfir.Item(blob)
-    columns = _operands(dtype, tiny_numerators=(mode != "shared"))
+#  fp32 quotients go through fp64 (prelude.hpp) and carry no condition on the numerator: the tiny
+#  numerators are part of every fp32 run
+    columns = _operands(dtype, tiny_numerators=(mode != "shared" or dtype == "f32"))
     rays = columns[0].size
 
     context = Context(0)
@@ -83,7 +86,8 @@ def test_division_at_the_edges_is_the_ieee_quotient(monkeypatch, tmp_path, dtype
                 assert _same(got, want), (key, launch_steps, np.flatnonzero(_bits(got) != _bits(want))[:8])
 #  Lanes did leave the window (bit 0) and stored zeros that came from quotients (bit 1): the status
 #  bits say that the IEEE function ran (never in `ieee` mode, which has no other path).
-    assert context.flags() == (0 if mode == "ieee" else 3)
+#  fp32 has no stored-zero rule (the fp64 product carries the IEEE sign of a zero): bit 0 only.
+    assert context.flags() == (0 if mode == "ieee" else (3 if dtype == "f64" else 1))
     context.close()
 
 
