@@ -378,6 +378,8 @@ struct equilibrium_base {
         return i == 0 ? graph::vector(one, zero, zero)
              : (i == 1 ? graph::vector(zero, one, zero) : graph::vector(zero, zero, one));
     }
+//  ... as functions of the coordinates, for equilibria in generalised coordinates (vmec).
+    virtual vec3<T, S> esup_at(const int i, leaf<T, S>, leaf<T, S>, leaf<T, S>) { return esup(i); }
 };
 
 // ---------------------------------------------------------------------------
@@ -483,6 +485,175 @@ public:
     leaf<T, S> get_electron_temperature(leaf<T, S> x, leaf<T, S> y, leaf<T, S> z) override { set_cache(x, y, z); return te_cache; }
     leaf<T, S> get_ion_temperature(leaf<T, S> x, leaf<T, S> y, leaf<T, S> z) override { set_cache(x, y, z); return ti_cache; }
     vec3<T, S> get_magnetic_field(leaf<T, S> x, leaf<T, S> y, leaf<T, S> z) override { set_cache(x, y, z); return b_cache; }
+};
+
+// ---------------------------------------------------------------------------
+// VMEC tables file written by tests/golden/make_vmec_golden.py: 5 doubles (sminh sminf ds dphi signj),
+// 3 uint64 (numsf numsh nummn), chi_c0..3 (numsf each), then per quantity and coefficient the nummn
+// rows: rmnc_c0..3, zmns_c0..3 (numsf per row), lmns_c0..3 (numsh per row), xm, xn.
+// ---------------------------------------------------------------------------
+struct raw_vmec {
+    double scalars[5];
+    uint64_t numsf, numsh, nummn;
+    std::vector<double> chi[4], xm, xn;
+    std::vector<std::vector<double>> rmnc[4], zmns[4], lmns[4];
+
+    explicit raw_vmec(const char *path) {
+        FILE *f = fopen(path, "rb");
+        if (!f) { perror(path); exit(1); }
+        auto rd = [f] (void *p, size_t bytes) { if (fread(p, 1, bytes, f) != bytes) { fprintf(stderr, "short read\n"); exit(1); } };
+        rd(scalars, sizeof(scalars));
+        rd(&numsf, 8); rd(&numsh, 8); rd(&nummn, 8);
+        for (auto &c : chi) { c.resize(numsf); rd(c.data(), 8*numsf); }
+        for (auto *q : {rmnc, zmns, lmns}) {
+            const size_t length = q == lmns ? numsh : numsf;
+            for (int k = 0; k < 4; k++) {
+                q[k].assign(nummn, std::vector<double> (length));
+                for (auto &row : q[k]) rd(row.data(), 8*length);
+            }
+        }
+        xm.resize(nummn); rd(xm.data(), 8*nummn);
+        xn.resize(nummn); rd(xn.data(), 8*nummn);
+        fclose(f);
+    }
+};
+
+// ---------------------------------------------------------------------------
+// Restatement of equilibrium::vmec (equilibrium.hpp:1868-2330) against the reference node API:
+// flux coordinates (s, u, v), R, Z, lambda as Fourier sums over `nummn` modes of cubic splines in s,
+// covariant basis from df(), contravariant basis and B from the Jacobian.
+// ---------------------------------------------------------------------------
+template<typename T, bool S=false>
+class vmec : public equilibrium_base<T, S> {
+public:
+    T sminh, sminf, ds;
+    leaf<T, S> signj, dphi;
+    backend::buffer<T> chi_c[4];
+    std::vector<backend::buffer<T>> rmnc_c[4], zmns_c[4], lmns_c[4];
+    std::vector<T> xm, xn;
+    size_t modes;
+
+    leaf<T, S> s_cache, u_cache, v_cache, x_cache, y_cache, z_cache;
+    vec3<T, S> esups_cache, esupu_cache, esupv_cache, bvec_cache;
+
+    static backend::buffer<T> to_buffer(const std::vector<double> &v) {
+        return backend::buffer<T> (std::vector<T> (v.begin(), v.end()));
+    }
+
+    explicit vmec(const raw_vmec &raw, const size_t use_modes = 0) {        // make_vmec :2332-2650
+        sminh = static_cast<T> (raw.scalars[0]);
+        sminf = static_cast<T> (raw.scalars[1]);
+        ds = static_cast<T> (raw.scalars[2]);
+        dphi = graph::constant<T, S> (static_cast<T> (raw.scalars[3]));
+        signj = graph::constant<T, S> (static_cast<T> (raw.scalars[4]));
+        modes = use_modes ? std::min<size_t> (use_modes, raw.nummn) : raw.nummn;
+        for (int k = 0; k < 4; k++) {
+            chi_c[k] = to_buffer(raw.chi[k]);
+            for (size_t i = 0; i < modes; i++) {
+                rmnc_c[k].push_back(to_buffer(raw.rmnc[k][i]));
+                zmns_c[k].push_back(to_buffer(raw.zmns[k][i]));
+                lmns_c[k].push_back(to_buffer(raw.lmns[k][i]));
+            }
+        }
+        xm.assign(raw.xm.begin(), raw.xm.end());
+        xn.assign(raw.xn.begin(), raw.xn.end());
+        auto zero = graph::zero<T, S> ();                                   // :2212-2215
+        s_cache = zero; u_cache = zero; v_cache = zero;
+    }
+
+    static leaf<T, S> spline(std::vector<leaf<T, S>> cc, leaf<T, S> x, const T scale, const T offset) {
+        return efit<T, S>::build_1D_spline(cc, x, scale, offset);           // equilibrium.hpp:1121-1131
+    }
+
+    vec3<T, S> rotate(vec3<T, S> column) {                                  // get_esubs/u/v :1920-1975
+        auto cosv = graph::cos(v_cache);
+        auto sinv = graph::sin(v_cache);
+        auto one = graph::one<T, S> ();
+        auto zero = graph::zero<T, S> ();
+        auto m = graph::matrix(graph::vector(cosv, -sinv, zero),
+                               graph::vector(sinv, cosv,  zero),
+                               graph::vector(zero, zero,  one ));
+        return m->dot(column);
+    }
+
+    leaf<T, S> get_chi(leaf<T, S> s) {                                      // :1984-1992
+        auto c0 = graph::piecewise_1D(chi_c[0], s, ds, sminf);
+        auto c1 = graph::piecewise_1D(chi_c[1], s, ds, sminf);
+        auto c2 = graph::piecewise_1D(chi_c[2], s, ds, sminf);
+        auto c3 = graph::piecewise_1D(chi_c[3], s, ds, sminf);
+        return spline({c0, c1, c2, c3}, s, ds, sminf);
+    }
+
+    void set_cache(leaf<T, S> s, leaf<T, S> u, leaf<T, S> v) {              // :1999-2074
+        if (!s->is_match(s_cache) || !u->is_match(u_cache) || !v->is_match(v_cache)) {
+            s_cache = s; u_cache = u; v_cache = v;
+
+            auto s_norm_f = (s - sminf)/ds;
+
+            auto zero = graph::zero<T, S> ();
+            auto r = zero;
+            auto z = zero;
+            auto l = zero;
+
+            for (size_t i = 0; i < modes; i++) {
+                auto rmnc = spline({graph::piecewise_1D(rmnc_c[0][i], s, ds, sminf), graph::piecewise_1D(rmnc_c[1][i], s, ds, sminf),
+                                    graph::piecewise_1D(rmnc_c[2][i], s, ds, sminf), graph::piecewise_1D(rmnc_c[3][i], s, ds, sminf)},
+                                   s, ds, sminf);
+                auto zmns = spline({graph::piecewise_1D(zmns_c[0][i], s, ds, sminf), graph::piecewise_1D(zmns_c[1][i], s, ds, sminf),
+                                    graph::piecewise_1D(zmns_c[2][i], s, ds, sminf), graph::piecewise_1D(zmns_c[3][i], s, ds, sminf)},
+                                   s, ds, sminf);
+                auto lmns = spline({graph::piecewise_1D(lmns_c[0][i], s, ds, sminh), graph::piecewise_1D(lmns_c[1][i], s, ds, sminh),
+                                    graph::piecewise_1D(lmns_c[2][i], s, ds, sminh), graph::piecewise_1D(lmns_c[3][i], s, ds, sminh)},
+                                   s, ds, sminh);
+
+                auto m = graph::constant<T, S> (xm[i]);
+                auto n = graph::constant<T, S> (xn[i]);
+
+                auto sinmn = graph::sin(m*u - n*v);
+
+                r = r + rmnc*graph::cos(m*u - n*v);
+                z = z + zmns*sinmn;
+                l = l + lmns*sinmn;
+            }
+
+            x_cache = r*graph::cos(v);
+            y_cache = r*graph::sin(v);
+            z_cache = z;
+
+            auto esubs = rotate(graph::vector(r->df(s_cache), zero, z->df(s_cache)));
+            auto esubu = rotate(graph::vector(r->df(u_cache), zero, z->df(u_cache)));
+            auto esubv = rotate(graph::vector(r->df(v_cache), r,    z->df(v_cache)));
+
+            auto jacobian = esubs->dot(esubu->cross(esubv));
+
+            esups_cache = esubu->cross(esubv)/jacobian;
+            esupu_cache = esubv->cross(esubs)/jacobian;
+            esupv_cache = esubs->cross(esubu)/jacobian;
+
+            auto phip = (signj*dphi*s)->df(s);
+            auto jbsupu = get_chi(s_norm_f)->df(s) - phip*l->df(v);
+            auto jbsupv = phip*(1.0 + l->df(u));
+            bvec_cache = (jbsupu*esubu + jbsupv*esubv)/jacobian;
+        }
+    }
+
+    leaf<T, S> get_profile(leaf<T, S> s) {                                  // :2076-2079
+        return graph::pow((1.0 - graph::pow(graph::sqrt(s*s), 1.5)), 2.0);
+    }
+
+    vec3<T, S> esup_at(const int i, leaf<T, S> s, leaf<T, S> u, leaf<T, S> v) override {
+        set_cache(s, u, v);
+        return i == 0 ? esups_cache : (i == 1 ? esupu_cache : esupv_cache);
+    }
+    leaf<T, S> get_electron_density(leaf<T, S> s, leaf<T, S>, leaf<T, S>) override {
+        return graph::constant<T, S> (static_cast<T> (1.0E19))*get_profile(s);
+    }
+    leaf<T, S> get_ion_density(leaf<T, S> s, leaf<T, S> u, leaf<T, S> v) override { return get_electron_density(s, u, v); }
+    leaf<T, S> get_electron_temperature(leaf<T, S> s, leaf<T, S>, leaf<T, S>) override {
+        return graph::constant<T, S> (static_cast<T> (1000.0))*get_profile(s);
+    }
+    leaf<T, S> get_ion_temperature(leaf<T, S> s, leaf<T, S> u, leaf<T, S> v) override { return get_electron_temperature(s, u, v); }
+    vec3<T, S> get_magnetic_field(leaf<T, S> s, leaf<T, S> u, leaf<T, S> v) override { set_cache(s, u, v); return bvec_cache; }
 };
 
 // ---------------------------------------------------------------------------
@@ -595,7 +766,7 @@ struct dispersion_interface {
     dispersion_interface(leaf<T> w, leaf<T> kx, leaf<T> ky, leaf<T> kz,
                          leaf<T> x, leaf<T> y, leaf<T> z, equilibrium_base<T> &eq,
                          dispersion_function<T> f = cold_plasma_D<T>) :
-    k_vec(kx*eq.esup(0) + ky*eq.esup(1) + kz*eq.esup(2)),
+    k_vec(kx*eq.esup_at(0, x, y, z) + ky*eq.esup_at(1, x, y, z) + kz*eq.esup_at(2, x, y, z)),
     D(f(w, k_vec, x, y, z, eq, nullptr)), function(f) {
         auto dkdx = k_vec->df(x);
         auto dkdy = k_vec->df(y);

@@ -380,3 +380,20 @@ def test_root_finder_on_the_oracle_finds_the_reference_roots():
     assert np.array_equal(np.stack(got)[:3], want[:3]) and iterations[:3] == list(iterations_want[:3])
 #  where the wave is damped the two models agree on Im k within 15 % (record 6: the resonance)
     assert np.allclose(want[6].imag, golden["kamp"][6].imag, rtol=0.15)
+
+
+def test_vmec_field_on_the_oracle_matches_the_reference_bit_for_bit():
+    """equilibrium::vmec (equilibrium.hpp:1868-2330) on the reference-held spline file
+    graph_tests/vmec.nc — R, Z, lambda as sums over 86 Fourier modes of cubic splines in s, the
+    covariant basis from df(), B from the Jacobian; the double normalisation of get_chi's argument
+    (:2066, :1984-1992) is kept — at 64 points of flux-coordinate space: magnetic field, Cartesian
+    position, density and temperature, bit for bit against the reference graph layer's tape
+    (tests/golden/make_vmec_golden.py; sin/cos are the host libm's on both sides)."""
+    golden = np.load(os.path.join(GOLDEN, "vmec_golden.npz"))
+    item = gfir.Item(os.path.join(WORKLOADS, "vmec_field_kernel_f64.gfir"))
+    outs, _ = item.run([c.copy() for c in golden["inputs"]])
+    assert len(outs) == 8
+    for got, want in zip(outs, golden["outputs"]):
+        assert np.array_equal(got, want)
+    x, y, z = golden["outputs"][3:6]
+    assert 0.5 < np.hypot(x, y).min() and np.hypot(x, y).max() < 1.0 and np.abs(z).max() < 0.4     # a torus of major radius ~0.75 m
