@@ -110,3 +110,39 @@ def test_in_window_operands_never_take_the_second_body():
     for key, want in zip(["x", "q0", "mix"], [expected[4], expected_out[0], expected_out[4]]):
         assert np.array_equal(context.copy_to_host(key, np.empty(rays)), want), key
     context.close()
+
+
+def test_fp32_quotients_are_ieee_for_random_bit_patterns():
+    """fp32 quotients are rounded from an fp64 product (prelude.hpp).  The separation argument there
+    covers every finite numerator and every finite non-zero denominator; the lanes with zero, infinite
+    or NaN denominators take the IEEE function.  Here: four million operand pairs drawn as random BIT
+    PATTERNS (every exponent, subnormals, infinities and NaNs included) plus pairs built to land next to
+    rounding boundaries, against the host's IEEE division, bit for bit."""
+    from graph_framework_amd import Context
+    rng = np.random.default_rng(23)
+    b = gfir_random.Builder(rng, "f32", 2)
+    n_node, d_node = b.inputs
+    blob = gfir_random.serialize(b, [b.emit(gfir_random.DIV, n_node, d_node)], [], 2, "quotient")
+    count = 4*1024*1024
+    n = rng.integers(0, 2**32, count, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    d = rng.integers(0, 2**32, count, dtype=np.uint64).astype(np.uint32).view(np.float32)
+#  quotients next to a boundary: n = fl(m*d) for m a float or a midpoint of two floats, then one ulp off
+    m = rng.uniform(1.0, 2.0, 65536).astype(np.float32)
+    half = (m.astype(np.float64) + np.spacing(m).astype(np.float64)/2)
+    dd = rng.uniform(1.0, 2.0, 65536).astype(np.float32)
+    near = (half*dd.astype(np.float64)).astype(np.float32)
+    n[:65536], d[:65536] = near, dd
+    n[65536:131072], d[65536:131072] = np.nextafter(near, np.float32(4.0)), dd
+    n[131072:196608], d[131072:196608] = (m.astype(np.float64)*dd.astype(np.float64)).astype(np.float32), dd
+    context = Context(0)
+    kernel = context.add_kernel(blob, count)
+    context.compile()
+    kernel.create_kernel_call(["n", "d"], ["q"], [n, d])
+    kernel.run(1)
+    context.wait()
+    got = context.copy_to_host("q", np.empty(count, dtype=np.float32))
+    context.close()
+    with np.errstate(all="ignore"):
+        want = n/d
+    assert _same(got, want), np.flatnonzero(_bits(got) != _bits(want))[:8]
+    assert np.isnan(want).sum() > 1000 and (np.abs(want) < np.finfo(np.float32).tiny).sum() > 1000   # the sample does reach the edges
