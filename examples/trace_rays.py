@@ -4,7 +4,7 @@ graph_driver/xrays.cpp:419-461 (per device: initial distribution, Newton solve f
 with a record every `sub_steps`, result<rank>.nc) on the MI355X backend.
 
     python examples/trace_rays.py --rays 100000 --steps 1000 --sub-steps 100 [--output /tmp/rays]
-    python examples/trace_rays.py --rays 10000 --steps 2000 --sub-steps 100 --output /tmp/rays --absorption-model weak_damping
+    python examples/trace_rays.py --rays 10000 --dispersion ordinary_wave --steps 20000 --sub-steps 1000 --output /tmp/rays --absorption-model weak_damping
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/trace_rays.py ...
 
 One process per GPU; the ensemble is split as the reference splits it over device threads; every rank
@@ -27,6 +27,8 @@ def main():
     parser.add_argument("--steps", type=int, default=1000)
     parser.add_argument("--sub-steps", type=int, default=100, help="steps between trajectory records")
     parser.add_argument("--output", default=None, help="prefix of the result files (default: no output)")
+    parser.add_argument("--dispersion", choices=["cold_plasma", "ordinary_wave"], default="cold_plasma",
+                        help="exported combinations: cold_plasma (dt = 1e-3, xrays_bench) and ordinary_wave (dt = 1e-4, the CLI example's)")
     parser.add_argument("--absorption-model", choices=["weak_damping", "root_find"], default=None,
                         help="after the trace: kamp and power into the result file (needs --output)")
     args = parser.parse_args()
@@ -39,7 +41,8 @@ def main():
     rank, world, local_rank = distributed.init()
     torch.cuda.set_device(local_rank)
     begin, end = shard_bounds(args.rays, world, rank)
-    solve = Rk4ColdPlasmaEfit(cli_distribution(end - begin, seed=rank), index=local_rank, device_state=True)
+    solve = Rk4ColdPlasmaEfit(cli_distribution(end - begin, seed=rank), index=local_rank, device_state=True,
+                              dispersion=args.dispersion)
     residual = solve.init("kx")
     solve.compile()
     writer = TrajectoryWriter(solve, "%s%d.nc" % (args.output, rank)) if args.output else None
@@ -75,8 +78,10 @@ def main():
         result = ResultFile(path)
         power = result.read("power", records)
         result.close()
-        print("rank %d: absorption (%s) + power over %d records in %.3f s; transmitted power of the beam %.4f"
-              % (rank, args.absorption_model, records + 1, elapsed, float(np.nanmean(power))))
+        kept = power[np.isfinite(power) & (power <= 1.0)]
+        print("rank %d: absorption (%s) + power over %d records in %.3f s; transmitted power %.4f (mean over %d of %d rays "
+              "with a power in [0, 1])" % (rank, args.absorption_model, records + 1, elapsed,
+                                          float(kept.mean()) if kept.size else float("nan"), kept.size, power.size))
 
 
 if __name__ == "__main__":
