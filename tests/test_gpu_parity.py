@@ -109,10 +109,11 @@ def test_bench_ray_newton_and_1000_steps_match_reference():
     golden = dict(t=1.0000000000000007, x=2.6503724167948581, y=1.3098653092768473e-05,
                   z=5.7992231932273706e-04, kx=499.75806004711882, ky=2.4699010015446147e-03,
                   kz=2.7212694836099862)
+#  Bit for bit: on this ray no pow(x, 1.5) rounding difference reaches the state in 1000 steps.
     for k, v in golden.items():
         assert np.all(host[k] == host[k][0])
-        assert abs(host[k][0] - v) <= 1.0e-6*abs(v), (k, host[k][0], v)
-    assert abs(solve.check_residual(0) - 7.7779641626949096e-13) <= 1.0e-6*7.7779641626949096e-13
+        assert host[k][0] == v, (k, float(host[k][0]).hex(), float(v).hex())
+    assert solve.check_residual(0) == 7.7779641626949096e-13
 
 
 def test_solver_kernel_random_rays_vs_oracle():
