@@ -43,9 +43,11 @@ def prebuild_kernel(gfir_path, force=False):
 
 
 def prebuild_workloads(force=False):
-    built = []
-    for path in sorted(glob.glob(os.path.join(_lib.WORKLOAD_DIR, "*.gfir"))):
-        built.append(prebuild_kernel(path, force))
+#  hipcc takes seconds to a minute per item (the 86-mode VMEC field item): a few at a time.
+    from concurrent.futures import ThreadPoolExecutor
+    paths = sorted(glob.glob(os.path.join(_lib.WORKLOAD_DIR, "*.gfir")))
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        built = list(pool.map(lambda path: prebuild_kernel(path, force), paths))
 #  Drop code objects of earlier lowerings (the cache key is the source hash).
     keep = {os.path.splitext(b)[0] for b in built}
     for stale in glob.glob(os.path.join(_lib.CACHE_DIR, "*")):
