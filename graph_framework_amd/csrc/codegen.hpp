@@ -481,7 +481,11 @@ struct kernel_writer {
             for (auto &ch : symbol) {
                 if (ch == '\\' || ch == '\n' || ch == '\r') ch = ' ';
             }
-            s << "        real v" << i << " = in" << i << "[i];  // " << symbol << "\n";
+            if ((opt.nontemporal == 1 || opt.nontemporal == 3) && !cx) {
+                s << "        real v" << i << " = __builtin_nontemporal_load(in" << i << " + i);  // " << symbol << "\n";
+            } else {
+                s << "        real v" << i << " = in" << i << "[i];  // " << symbol << "\n";
+            }
         }
         for (size_t o = 0; o < it.outputs.size(); o++) {
             s << "        real o" << o << " = " << value_literal(0.0) << ";\n";
@@ -603,10 +607,19 @@ struct kernel_writer {
     void stores(const entry which) {
 //  Stores: setters first, then outputs (cpu_context.hpp:522-580).
         for (size_t i = 0; i < it.symbols.size(); i++) {
-            if (out.input_written[i]) s << "        in" << i << "[i] = v" << i << ";\n";
+            if (!out.input_written[i]) continue;
+            if ((opt.nontemporal == 1 || opt.nontemporal == 2) && !cx) {
+                s << "        __builtin_nontemporal_store(v" << i << ", in" << i << " + i);\n";
+            } else {
+                s << "        in" << i << "[i] = v" << i << ";\n";
+            }
         }
         for (size_t o = 0; o < it.outputs.size(); o++) {
-            s << "        out" << o << "[i] = o" << o << ";\n";
+            if ((opt.nontemporal == 1 || opt.nontemporal == 2) && !cx) {
+                s << "        __builtin_nontemporal_store(o" << o << ", out" << o << " + i);\n";
+            } else {
+                s << "        out" << o << "[i] = o" << o << ";\n";
+            }
         }
         if (which == entry::max) {
 //  The max of the last output (create_max_call's argument) as cpu_context takes it — std::max_element,
@@ -712,7 +725,9 @@ inline lowered lower(const item &original, const codegen_options &opt = codegen_
     const bool small = it.code.size() <= 1500;
     out.has_max = !it.outputs.empty() && small && !it.is_complex() && !it.has_random();
     out.has_converge = out.has_max && !it.setters.empty();
-    kernel_writer writer{s, it, opt, out, parent, factor, table_pack, table_column, plan, lds_used, park_offset, park_slots,
+    codegen_options resolved = opt;
+    if (resolved.nontemporal < 0) resolved.nontemporal = it.code.size() >= 100 ? 1 : 0;
+    kernel_writer writer{s, it, resolved, out, parent, factor, table_pack, table_column, plan, lds_used, park_offset, park_slots,
                          use_shared, after_division};
     if (park_slots) s << "typedef __attribute__((address_space(3))) real park_t;\n";
     if (use_shared) writer.ieee_function();
