@@ -147,3 +147,28 @@ def test_root_finder_pass_over_a_trajectory_file(tmp_path):
     assert root_finder_matches(kamp, np.stack(expected), model.iterations, iterations) >= 15
 #  outside the plasma nothing but exact arithmetic is involved: same bits, same iteration counts
     assert np.array_equal(kamp[:3], np.stack(expected)[:3]) and list(model.iterations[:3]) == iterations[:3]
+
+
+def test_example_runs_the_three_stages_of_xrays(tmp_path):
+    """examples/trace_rays.py: trace (rk4 x ordinary_wave on EFIT, the CLI beam) -> kamp -> power on one
+    trajectory file, as graph_driver/xrays.cpp:1100-1105 chains them."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    from graph_framework_amd.output import ResultFile
+    prefix = str(tmp_path / "rays")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "trace_rays.py"), "--rays", "512", "--dispersion",
+                          "ordinary_wave", "--steps", "20000", "--sub-steps", "2000", "--output", prefix,
+                          "--absorption-model", "weak_damping"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "transmitted power" in out.stdout
+    result = ResultFile(prefix + "0.nc")
+    assert result.records == 11 and result.num_rays == 512
+    power = result.read("power", 10)
+    x_first, x_last = result.read("x", 0), result.read("x", 10)
+    kamp_imag = np.stack([result.read("kamp", r, part=1) for r in range(11)])
+    result.close()
+    assert np.isfinite(x_last).all() and (x_last < x_first).all()             # the beam travels inward
+    assert np.isfinite(kamp_imag).all() and kamp_imag.max() > 1.0              # and crosses the resonance
+    absorbed = np.isfinite(power) & (power < 0.9)
+    assert absorbed.sum() > 256, absorbed.sum()
