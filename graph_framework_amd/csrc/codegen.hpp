@@ -540,7 +540,7 @@ struct kernel_writer {
             const char *high = f64 ? "0x1p+500" : "0x1.fffffep+127f";
             s << "                bad = " << (f64 ? "!(vmax < __builtin_inff()) || " : "") << "!(dmin >= gf_magnitude(" << low
               << ")) || !(dmax <= gf_magnitude(" << high << "))";
-            if (track_numerators) s << " || nmin < gf_numerator_key(" << (f64 ? "0x1p-450" : "0x1p-60f") << ")";
+            if (track_numerators) s << " || nmin < gf_numerator_key(0x1p-450)";     // fp64 only (track_numerators)
             s << ";\n";
 //  With v_div_fixup in the quotients the sign of a zero is the IEEE one and stored zeros need no
 //  second look (GFHIP_DIV_FIXUP=1: for ensembles that keep exact zeros in their state, e.g. a

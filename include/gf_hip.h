@@ -120,11 +120,11 @@ int gfhip_wait(gfhip_context *ctx);
 /* Status bits raised by kernels since the context was created (after a drain);
  * informational: the lanes concerned redid their pass with the compiler's IEEE
  * division, results are the IEEE ones either way.
- * Bit 0: a lane failed a window check of the shared-reciprocal division (a
- *        denominator outside [2^-500, 2^500] fp64 / [2^-100, 2^100] fp32, a
- *        non-finite result or gather index quotient).
- * Bit 1: a lane stored a zero computed from a quotient (its sign is only the IEEE
- *        one through v_div_fixup). */
+ * Bit 0: a lane failed a check of the shared-reciprocal division (fp64: a
+ *        denominator outside [2^-500, 2^500], a non-finite result or gather index
+ *        quotient; fp32: a zero, infinite or NaN denominator).
+ * Bit 1: fp64 only: a lane stored a zero computed from a quotient (its sign is only
+ *        the IEEE one through v_div_fixup). */
 int gfhip_get_flags(gfhip_context *ctx, unsigned int *flags);
 
 /* Whole-buffer copies, synchronous on return.  Replace copy_to_device /

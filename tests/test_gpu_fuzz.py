@@ -76,8 +76,7 @@ def test_alternative_lowerings_are_bit_exact(monkeypatch, tmp_path, option, valu
             expected_out, _ = oracle_item.run(expected, steps=launch_steps)
             kernel.run(launch_steps)
             context.wait()
-#  (`checked` also sends lanes with a numerator below 2^-450 / 2^-60 through the IEEE function:
-#  products of a few small random values get there in fp32)
+#  (`checked` also sends fp64 lanes with a numerator below 2^-450 through the IEEE function)
             assert context.flags() == 0 or value == "checked"
             for key, want in zip(in_keys + out_keys, expected + expected_out):
                 got = context.copy_to_host(key, np.empty(rays, dtype=oracle_item.np_dtype))
