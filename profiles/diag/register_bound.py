@@ -67,7 +67,10 @@ def main():
                     writes += resident[victim]
                 used_registers -= resident.pop(victim)
 
+        peak_spilled = 0
         for position, (name, registers, used) in enumerate(order):
+            alive_spilled = sum(1 for x in spilled if next_use(x, position) < (1 << 30))
+            peak_spilled = max(peak_spilled, alive_spilled)
             operands = [x for x in used if x in size and x in uses]
             for x in operands:
                 if x not in resident:                                   # reload
@@ -83,7 +86,8 @@ def main():
                 resident[name] = registers
                 used_registers += registers
         print("256 VGPRs, %2d kept for temporaries: %4d v_accvgpr_write + %4d v_accvgpr_read = %4d copies per pass "
-              "(hipcc: 256 + 428 = 684)" % (headroom, writes, reads, writes + reads))
+              "(hipcc: 256 + 428 = 684); at most %d spilled values alive at once (LDS slots, were they parked there: "
+              "%d ds_write + %d ds_read)" % (headroom, writes, reads, writes + reads, peak_spilled, writes//2, reads//2))
 
 
 if __name__ == "__main__":
