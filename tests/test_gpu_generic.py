@@ -230,3 +230,28 @@ def test_erfi_on_the_device_meets_the_reference_erfi_test(dtype, tolerance):
     oracle_values, _ = gfir.Item(blob).run([z.copy()])
     np.testing.assert_allclose(got, oracle_values[0], rtol=1.0e-13 if dtype == "c64" else 1.0e-5, atol=0.0)
     context.close()
+
+
+def test_erfi_branches_on_the_device():
+    """The branches erfi takes before its general formula (prelude.hpp, special_functions.hpp:1495-1517)
+    agree with the oracle's: arguments on the real axis give exactly real values (to 1e-13: exp and the
+    Weideman sum are the device libm's), on the imaginary axis i erf(y), Re(z^2) < -750 gives -+i."""
+    from graph_framework_amd import Context
+    it = Item("c64", False, ["z"], name="erfi_branches")
+    blob = it.blob([it.emit(ERFI, it.emit(INPUT, a=0))], [])
+    z = np.array([1.0e-3, 0.7, -3.0, 12.0, 26.0, -26.5, 27.0, -27.0, 0.3j, -2.0j, 7.5j, 1.0 + 28.0j, 1.0 - 28.0j,
+                  0.0, 5.0 + 1.0e-300j], dtype=np.complex128)
+    context = Context(0)
+    kernel = context.add_kernel(blob, z.size)
+    context.compile()
+    kernel.create_kernel_call(["z"], ["erfi"], [z])
+    kernel.run(1)
+    context.wait()
+    got = context.copy_to_host("erfi", np.empty(z.size, dtype=np.complex128))
+    context.close()
+    want = np.array([gfir.erfi(complex(v)) for v in z])
+    assert np.array_equal(got.imag[:8], np.zeros(8)) and np.array_equal(got.real[8:11], np.zeros(3))
+    np.testing.assert_allclose(got.real[:8], want.real[:8], rtol=1.0e-13, atol=0.0)
+    np.testing.assert_allclose(got.imag[8:11], want.imag[8:11], rtol=4.0e-16, atol=0.0)
+    assert np.array_equal(got[11:14], want[11:14])
+    np.testing.assert_allclose([got[14].real, got[14].imag], [want[14].real, want[14].imag], rtol=1.0e-12, atol=0.0)

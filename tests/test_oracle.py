@@ -397,3 +397,27 @@ def test_vmec_field_on_the_oracle_matches_the_reference_bit_for_bit():
         assert np.array_equal(got, want)
     x, y, z = golden["outputs"][3:6]
     assert 0.5 < np.hypot(x, y).min() and np.hypot(x, y).max() < 1.0 and np.abs(z).max() < 0.4     # a torus of major radius ~0.75 m
+
+
+def test_erfi_branches_taken_before_the_general_formula():
+    """The special cases of special::erf_complex (special_functions.hpp:1495-1517) the restatement keeps as
+    behaviour: erfi(iy) = i erf(y); erfi of a real argument is REAL (exp(x^2) Im w(x), the largest double
+    beyond x^2 = 720) — which is what gives Im Z(zeta) = sqrt(pi) exp(-zeta^2) its relative accuracy in the
+    absorption pass; Re(z^2) < -750 gives -+i."""
+    import math
+    for y in (0.3, -2.0, 7.5):
+        value = gfir.erfi(complex(0.0, y))
+        assert value.real == 0.0 and value.imag == math.erf(y)
+    for x in (1.0e-3, 0.7, 3.0, 12.0, 26.0):
+        value = gfir.erfi(complex(x, 0.0))
+        assert value.imag == 0.0
+#  erfi(x) = 2/sqrt(pi) * sum x^(2k+1)/(k! (2k+1)) for small x; exp(x^2)/(sqrt(pi) x) (1 + 1/(2x^2) + ...) for large
+        if x < 1.0:
+            series = 2.0/math.sqrt(math.pi)*sum(x**(2*k + 1)/(math.factorial(k)*(2*k + 1)) for k in range(30))
+            assert abs(value.real - series) <= 4.0e-15*abs(series)
+        elif x >= 12.0:
+            asymptotic = math.exp(x*x)/(math.sqrt(math.pi)*x)*(1.0 + 0.5/x**2 + 0.75/x**4 + 1.875/x**6)
+            assert abs(value.real - asymptotic) <= 1.0e-5*asymptotic
+        assert gfir.erfi(complex(-x, 0.0)).real == -value.real
+    assert gfir.erfi(complex(27.0, 0.0)).real == 1.7976931348623157e308 and gfir.erfi(complex(-27.0, -0.0)).real == -1.7976931348623157e308
+    assert gfir.erfi(complex(1.0, 28.0)) == complex(0.0, 1.0) and gfir.erfi(complex(1.0, -28.0)) == complex(0.0, -1.0)
