@@ -172,3 +172,43 @@ def test_example_runs_the_three_stages_of_xrays(tmp_path):
     assert np.isfinite(kamp_imag).all() and kamp_imag.max() > 1.0              # and crosses the resonance
     absorbed = np.isfinite(power) & (power < 0.9)
     assert absorbed.sum() > 256, absorbed.sum()
+
+
+def test_weak_damping_on_a_perturbed_ensemble():
+    """1e5 rays scattered around the golden trajectories (positions by up to 2 cm, wave vectors and
+    frequency by 1 %), so that zeta = (1 - ec/w)/(n_par v_t) sweeps through the resonance on many
+    distinct values: the device against the oracle, 1e-11 relative in each part of kamp (imaginary parts
+    below 1e-280 are compared absolutely: they are products of numbers that underflow on both sides)."""
+    from graph_framework_amd import Context
+    from oracle import gfir
+    golden = np.load(os.path.join(GOLDEN, "absorption_golden.npz"))
+    base = absorption_columns(golden["records"])
+    rng = np.random.default_rng(5)
+    n = 100000
+    pick = rng.integers(0, base[0].size, n)
+    columns = [np.zeros(n, dtype=np.complex128)]
+    for name, column in zip(INPUTS[1:], base[1:]):
+        values = column.real[pick].copy()
+        if name in ("x", "y", "z"):
+            values += rng.uniform(-0.02, 0.02, n)
+        elif name != "t":
+            values *= 1.0 + rng.uniform(-0.01, 0.01, n)
+        columns.append(values.astype(np.complex128))
+    path = os.path.join(WORKLOADS, "weak_damping_kimg_kernel_c64.gfir")
+    context = Context(0)
+    kernel = context.add_kernel(path, n)
+    context.compile()
+    kernel.create_kernel_call(INPUTS, [], columns)
+    kernel.run(1)
+    context.wait()
+    got = context.copy_to_host("kamp", np.empty(n, dtype=np.complex128))
+    context.close()
+    expected = [c.copy() for c in columns]
+    gfir.Item(path).run(expected, steps=1, threads=8)
+    want = expected[0]
+    assert np.array_equal(np.isfinite(got.real), np.isfinite(want.real))
+    ok = np.isfinite(want.real) & np.isfinite(want.imag)
+    assert ok.sum() > 0.99*n
+    np.testing.assert_allclose(got.real[ok], want.real[ok], rtol=1.0e-11, atol=0.0)
+    np.testing.assert_allclose(got.imag[ok], want.imag[ok], rtol=1.0e-11, atol=1.0e-280)
+    assert (np.abs(want.imag[ok]) > 1.0).sum() > 1000                # the resonance is inside the sample
