@@ -20,6 +20,10 @@ anything here touches the GPU — collects rank 0's line and exits non-zero if a
 the reference's own benchmark, which needs no launcher (one thread per device,
 xrays_bench.cpp:34-108).
 
+`--workload korc` runs the xkorc push instead (graph_korc/xkorc.cpp:29-154, fp32, BASELINE
+configs[4]: 1e7 particles, split over the ranks like the reference's device threads) and prints a
+line of the same shape with metric particle-steps/s.
+
 `value` is the step-loop rate (K launches between barrier + synchronize on both sides).  The
 reference's timed region also holds the final sync_host (8 D2H copies, xrays_bench.cpp:95-102);
 that PCIe-inclusive rate of the same run is `value_with_sync_host`.
@@ -70,6 +74,15 @@ def parse_arguments(argv=None):
                         help="no GPU: run only the multi-rank plumbing (rendezvous over gloo, item broadcast, shard "
                              "split, all-gather, max-over-ranks) and print a rehearsal line; covered by tests/")
     parser.add_argument("--fail-rank", type=int, default=-1, help="(rehearsal) this rank exits with an error")
+    parser.add_argument("--workload", choices=["rays", "korc"], default="rays",
+                        help="rays: the metric's workload (xrays_bench solver_kernel, fp64); korc: the xkorc particle "
+                             "push of BASELINE configs[4] (fp32; --gpus N > 1 splits 1e7 particles over the ranks as "
+                             "graph_korc/xkorc.cpp:16-25 splits them over its device threads) -- a second bench "
+                             "line with its own metric, never the headline")
+    parser.add_argument("--force-collectives", action="store_true",
+                        help="initialise the process group for ONE rank as well and run every collective through the "
+                             "backend (--gpus 1 --backend nccl --force-collectives executes the RCCL code path on a "
+                             "one-GPU box)")
     parser.add_argument("--distribution", choices=["bench", "cli"], default="bench",
                         help="bench: identical rays of xrays_bench.cpp:62-71 (the metric's workload); "
                              "cli: the incoherent example distribution of graph_driver/xrays.cpp (BASELINE configs[2])")
@@ -288,31 +301,189 @@ def rehearse_cpu(args):
     through the self-launcher (and through torch.distributed.run) on a CPU-only host."""
     import torch
     from graph_framework_amd import distributed as gfd
+    from graph_framework_amd import korc as gk
     from graph_framework_amd.xrays import STATE, shard_bounds, workload
-    rank, world, _ = gfd.init("gloo")
+    rank, world, _ = gfd.init("gloo", force_collectives=args.force_collectives)
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if rank == args.fail_rank:
         raise SystemExit("rank %d fails on request" % rank)
     total = args.total_rays or (args.rays_per_gpu*world if args.rays_per_gpu else 1003)
     begin, end = shard_bounds(total, world, rank)
-    data = b""
-    if rank == 0:
-        with open(workload("loss_kernel_kx"), "rb") as f:
-            data = f.read()
-    item = gfd.broadcast_bytes(data, 0)
+    if args.workload == "korc":
+        names, dtype, columns, torch_dtype = gk.ITEMS, "f32", gk.PARTICLE, torch.float32
+    else:
+        names, dtype, columns, torch_dtype = ("loss_kernel_kx",), "f64", STATE, torch.float64
+    item_bytes = 0
+    for name in names:
+        data = b""
+        if rank == 0:
+            with open(workload(name, dtype), "rb") as f:
+                data = f.read()
+        item = gfd.broadcast_bytes(data, 0)
+        with open(workload(name, dtype), "rb") as f:
+            assert item == f.read()
+        item_bytes += len(item)
     gathered = 0
-    for k in range(len(STATE)):
-        full = gfd.all_gather_shards(torch.arange(begin, end, dtype=torch.float64) + k, total)
-        assert torch.equal(full, torch.arange(total, dtype=torch.float64) + k)
+    for k in range(len(columns)):
+        full = gfd.all_gather_shards(torch.arange(begin, end, dtype=torch_dtype) + k, total)
+        assert torch.equal(full, torch.arange(total, dtype=torch_dtype) + k)
         gathered += full.numel()
     slowest = gfd.max_over_ranks(float(rank))
     gfd.barrier()
     if rank == 0:
-        print(json.dumps({"rehearsal": "cpu", "n_gpus": world, "total_rays": total, "item_bytes": len(item),
+        print(json.dumps({"rehearsal": "cpu", "workload": args.workload, "n_gpus": world, "total_rays": total,
+                          "item_bytes": item_bytes, "items": len(names),
                           "gathered_elements": gathered, "slowest_rank": slowest,
                           "launcher": os.environ.get("GF_BENCH_LAUNCHER", "torchrun")}))
         sys.stdout.flush()
+
+
+def collective_info(args):
+    """Which backend ran the collectives of this line (and that they were forced for one rank)."""
+    import torch
+    info = {"backend": torch.distributed.get_backend(), "forced_for_one_rank": bool(args.force_collectives)}
+    try:
+        info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+        info["rccl_version"] = None
+    return info
+
+
+def run_rank_korc(args):
+    """--workload korc: the xkorc push (graph_korc/xkorc.cpp:29-154) in fp32, one shard per rank.
+
+    The reference starts one host thread per device and gives thread i
+    `batch + (extra > i)` particles (xkorc.cpp:16-25), every thread building its own equilibrium and
+    characteristic field (:29-31) and its own workflow::manager(thread_number) (:74).  Here: one
+    process per GPU with the same split (shard_bounds), rank 0 reads the four work items and
+    broadcasts them (the `step` item carries the folded EFIT tables and b0), every rank solves the
+    characteristic field itself, runs the pre-item and steps independently; the seven particle
+    arrays are all-gathered from the device tensors at output cadence.  No per-step collective."""
+    import numpy as np
+    import torch
+    from graph_framework_amd import distributed as gfd
+    from graph_framework_amd import korc as gk
+    from graph_framework_amd.xrays import shard_bounds, workload
+
+    rank, world, local_rank = gfd.init(args.backend, device_index=0 if args.share_gpu else None,
+                                       force_collectives=args.force_collectives)
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.share_gpu:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    collectives = world > 1 or args.force_collectives
+
+    per_gpu, total = args.rays_per_gpu, args.total_rays
+    if not per_gpu and not total:
+        total = DEFAULT_RAYS_ONE_GPU                        # BASELINE configs[4]: 1e7 particles in all
+    strong = total > 0
+    if strong:
+        begin, end = shard_bounds(total, world, rank)
+        n_local = end - begin
+    else:
+        n_local, total = per_gpu, per_gpu*world
+        begin = rank*per_gpu
+
+    items = {}
+    for name in gk.ITEMS:
+        data = b""
+        if rank == 0:
+            with open(workload(name, "f32"), "rb") as f:
+                data = f.read()
+        items[name] = gfd.broadcast_bytes(data, 0)
+
+    b0, axis_iterations = gk.characteristic_field("f32", index=local_rank, items=items)
+#  xkorc.cpp:47-64: every particle x = (1.7, 0, 0), u = (0, 0.99, 0.1).
+    push = gk.Korc(dict(x=1.7, y=0.0, z=0.0, ux=0.0, uy=0.99, uz=0.1, gamma=np.zeros(n_local)), "f32",
+                   index=local_rank, items=items, device_state=True)
+    push.compile()
+    push.pre_run()
+    warm_start = time.perf_counter()
+    warm_steps = 0
+    for _ in range(args.warmup):
+        push.run()
+        warm_steps += 1
+    torch.cuda.synchronize()
+    while time.perf_counter() - warm_start < args.warmup_seconds:
+        for _ in range(10):
+            push.run()
+        warm_steps += 10
+        torch.cuda.synchronize()
+    timing_period = 8 if args.steps >= 64 else 1
+    push.work.context.enable_timing(True, every=timing_period)
+
+    gfd.barrier()
+    torch.cuda.synchronize()
+    start = time.perf_counter()
+    for _ in range(args.steps):
+        push.run()
+    torch.cuda.synchronize()
+    gfd.barrier()
+    elapsed = gfd.max_over_ranks(time.perf_counter() - start)
+    samples = push.step_item.kernel.timing_samples()
+    kernel_ms = gfd.max_over_ranks(sum(samples)/len(samples) if samples else 0.0)
+    push.work.context.enable_timing(False)
+
+    gather_seconds = None
+    checksum = None
+    if collectives:
+        on_device = torch.distributed.get_backend() == "nccl"
+        torch.cuda.synchronize()
+        gfd.barrier()
+        t0 = time.perf_counter()
+        checksum = 0.0
+        for k in gk.PARTICLE:
+            shard = push.device[k] if on_device else push.device[k].cpu()
+            full = gfd.all_gather_shards(shard, total)
+            assert full.numel() == total
+            checksum += float(full.double().sum().item())
+            del full
+        torch.cuda.synchronize()
+        gather_seconds = gfd.max_over_ranks(time.perf_counter() - t0)
+
+    if rank != 0:
+        return
+    info = push.step_item.kernel.info()
+    name = info.name.decode()
+    achieved = n_local*BYTES_PER_PARTICLE_STEP_F32/(kernel_ms*1.0e-3)/1.0e9 if kernel_ms > 0 else 0.0
+    distributed_info = {"world_size": world, "launcher": os.environ.get("GF_BENCH_LAUNCHER", "torchrun" if world > 1 else "none")}
+    if collectives:
+        distributed_info.update(collective_info(args))
+    line = {
+        "metric": "particle-steps/sec on the xkorc push (BASELINE configs[4]); achieved HBM GB/s vs peak",
+        "value": total*args.steps/elapsed,
+        "unit": "particle-steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1.0e3*elapsed/args.steps,
+        "higher_is_better": True,
+        "scaling": "strong" if strong else "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "xkorc relativistic push `step` on EFIT (efit.nc), x=(1.7,0,0) u=(0,0.99,0.1) dt=0.5, fp32 "
+                               "(graph_korc/xkorc.cpp:47-121)",
+                   "particles_per_gpu": n_local, "total_particles": total,
+                   "parallelism": "particles sharded x%d (xkorc.cpp:16-25)" % world,
+                   "kernel_nodes": int(info.num_instructions), "vgprs": int(info.vgprs),
+                   "code_object_from_cache": bool(info.from_cache), "warmup_steps_run": warm_steps,
+                   "b0": b0, "axis_newton_iterations": axis_iterations},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved/HBM_PEAK_GBPS, "traffic": measured_traffic(name, info.source_hash, n_local),
+                     "kernel": name, "kernel_ms": kernel_ms, "launches": len(samples), "timed_every": timing_period,
+                     "algorithmic_bytes_per_launch": n_local*BYTES_PER_PARTICLE_STEP_F32,
+                     "source_hash": "%016x" % info.source_hash},
+        "distributed": distributed_info,
+    }
+    if gather_seconds is not None:
+        line["all_gather_seconds"] = gather_seconds
+        line["all_gather_bytes"] = total*4*len(gk.PARTICLE)
+        line["all_gather_checksum"] = checksum
+    print(json.dumps(line))
+    sys.stdout.flush()
 
 
 def run_rank(args):
@@ -321,12 +492,14 @@ def run_rank(args):
     from graph_framework_amd import distributed as gfd
     from graph_framework_amd.xrays import Rk4ColdPlasmaEfit, STATE, shard_bounds, workload
 
-    rank, world, local_rank = gfd.init(args.backend, device_index=0 if args.share_gpu else None)
+    rank, world, local_rank = gfd.init(args.backend, device_index=0 if args.share_gpu else None,
+                                       force_collectives=args.force_collectives)
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    collectives = world > 1 or args.force_collectives
 
     rays_per_gpu, total_rays = args.rays_per_gpu, args.total_rays
     if not rays_per_gpu and not total_rays:
@@ -408,7 +581,7 @@ def run_rank(args):
 #  Output-cadence collective: all-gather of the trajectory state over xGMI, from the device
 #  tensors the kernels write (not in the step loop; gloo rehearsals gather host copies).
     gather_seconds = None
-    if world > 1:
+    if collectives:
         on_device = torch.distributed.get_backend() == "nccl"
         torch.cuda.synchronize()
         gfd.barrier()
@@ -449,12 +622,8 @@ def run_rank(args):
     name = info.name.decode()
     achieved = n_local*BYTES_PER_RAY_STEP_F64/(kernel_ms*1.0e-3)/1.0e9 if kernel_ms > 0 else 0.0
     distributed_info = {"world_size": world, "launcher": os.environ.get("GF_BENCH_LAUNCHER", "torchrun" if world > 1 else "none")}
-    if world > 1:
-        distributed_info["backend"] = torch.distributed.get_backend()
-        try:
-            distributed_info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
-        except Exception:
-            distributed_info["rccl_version"] = None
+    if collectives:
+        distributed_info.update(collective_info(args))
     line = {
         "metric": "ray-steps/sec on xrays_bench cold-plasma; achieved HBM GB/s vs peak",
         "value": value,
@@ -511,12 +680,24 @@ def run_rank(args):
 
 def main():
     args = parse_arguments()
+    if args.force_collectives and args.gpus == 1:
+#  A one-rank group still needs a rendezvous address.
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
 #  No launcher around us: become the launcher.  Nothing above has imported torch or touched HIP.
         os.environ["GF_BENCH_LAUNCHER"] = "bench.py"
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+#  stdout is ONE JSON line: libraries announce themselves on file descriptor 1 (RCCL prints its
+#  version banner there, gloo its connections), so descriptor 1 is pointed at stderr for the life
+#  of the rank and Python's sys.stdout keeps the real one.
+    sys.stdout.flush()
+    sys.stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     if args.rehearse_cpu:
         rehearse_cpu(args)
+    elif args.workload == "korc":
+        run_rank_korc(args)
     else:
         run_rank(args)
     try:

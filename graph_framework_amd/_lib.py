@@ -35,6 +35,7 @@ _P, _S, _U64, _U32, _I = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint64, ctyp
 SYMBOLS = [
     ("gfhip_max_concurrency", _I, []),
     ("gfhip_device_type", ctypes.c_char_p, []),
+    ("gfhip_shard_bounds", _I, [_S, _S, _S, ctypes.POINTER(_S), ctypes.POINTER(_S)]),
     ("gfhip_create_context", _P, [_I, _P]),
     ("gfhip_destroy_context", None, [_P]),
     ("gfhip_last_error", ctypes.c_char_p, [_P]),
@@ -44,6 +45,7 @@ SYMBOLS = [
     ("gfhip_run", _I, [_P, _U32]),
     ("gfhip_run_max", _I, [_P, ctypes.POINTER(ctypes.c_double)]),
     ("gfhip_run_max_complex", _I, [_P, ctypes.POINTER(ctypes.c_double)]),
+    ("gfhip_reduce_max", _I, [_P, _U64, ctypes.POINTER(ctypes.c_double)]),
     ("gfhip_converge", _I, [_P, ctypes.c_double, _S, ctypes.POINTER(_S), ctypes.POINTER(ctypes.c_double)]),
     ("gfhip_converge_per_ray", _I, [_P, ctypes.c_double, _S, ctypes.POINTER(_S), ctypes.POINTER(ctypes.c_double)]),
     ("gfhip_wait", _I, [_P]),

@@ -186,7 +186,10 @@ class Kernel:
                     raise ValueError("initial values of %r: %d elements for %d rays" % (key, value.size, self.num_rays))
                 keep.append(value)
                 init[i] = value.ctypes.data
-                counts[i] = self.num_rays
+#  The value's own length: an input that index_1D/2D nodes read may be longer than the ensemble
+#  (hip_context passes buffer.size() the same way); the C side allocates max(num_rays, indexed
+#  length, this) and rejects a value shorter than what the index nodes address.
+                counts[i] = value.size
         self.context._check(self.lib.gfhip_create_kernel_call(self.handle, in_keys, init, counts, out_keys))
 
     def set_random_state(self, key, states):

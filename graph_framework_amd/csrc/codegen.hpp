@@ -277,6 +277,17 @@ struct kernel_writer {
                     break;
                 }
                 case GFIR_POW:
+//  pow tells -0 from +0 when the exponent is an odd integer (pow(-0, -1) = -inf, pow(+0, -1) = +inf): a base
+//  that comes from a shared-reciprocal quotient (whose zero may carry the wrong sign without v_div_fixup) joins
+//  the zero check unless the exponent is a constant that is not an odd integer.
+                    if (shared && f64 && !fixup && after_division[c.a]) {
+                        const gfir_instruction &e = it.code[c.b];
+                        const bool harmless = e.op == GFIR_CONST &&
+                                              !(e.imm[0] == std::floor(e.imm[0]) && std::fmod(std::fabs(e.imm[0]), 2.0) == 1.0);
+                        if (!harmless) {
+                            s << ind << "zmin = __builtin_elementwise_minimum(zmin, gf_magnitude(" << N(c.a) << "));\n";
+                        }
+                    }
                     if (f64 && !generic && opt.pow_three_halves && it.code[c.b].op == GFIR_CONST && it.code[c.b].imm[0] == 1.5) {
                         s << ind << "const real r" << i << " = gf_pow_three_halves(" << N(c.a) << ");\n";
                     } else {
@@ -520,6 +531,7 @@ struct kernel_writer {
             s << "            {\n";
             s << "                float dmax = gf_magnitude(" << literal(1.0) << "), dmin = dmax;   // extreme |denominator| of this pass\n";
             if (f64) s << "                float vmax = dmax;                                   // extreme |stored value|, |index quotient|\n";
+            if (f64 && !fixup) s << "                float zmin = __builtin_inff();                       // smallest |value| whose zero would be observed\n";
             if (track_numerators) s << "                unsigned int nmin = 0xFFFFFFFFu;                    // smallest non-zero |numerator| key\n";
             body(true);
 //  The finite checks run on the same fp32 image as the window check (a non-finite value, or a
@@ -546,8 +558,7 @@ struct kernel_writer {
 //  second look (GFHIP_DIV_FIXUP=1: for ensembles that keep exact zeros in their state, e.g. a
 //  symmetry plane, where this check would send every pass through the IEEE function).
 //  (the image of a double below 2^-1042 is zero as well: such a value takes the IEEE function too)
-            if (!fixup && !quotient_results.empty()) {
-                s << "                float zmin = __builtin_inff();\n";
+            if (f64 && !fixup) {
                 for (auto &value : quotient_results) {
                     s << "                zmin = __builtin_elementwise_minimum(zmin, gf_magnitude(" << value << "));\n";
                 }

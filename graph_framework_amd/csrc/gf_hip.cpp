@@ -149,6 +149,16 @@ extern "C" const char *gfhip_device_type(void) {
     return "HIP GPU";
 }
 
+extern "C" int gfhip_shard_bounds(size_t total, size_t shards, size_t index, size_t *begin, size_t *end) {
+    if (shards == 0 || index >= shards) return 1;
+    const size_t batch = total/shards;
+    const size_t extra = total%shards;
+    const size_t first = index*batch + (index < extra ? index : extra);
+    if (begin) *begin = first;
+    if (end) *end = first + batch + (extra > index ? 1 : 0);
+    return 0;
+}
+
 extern "C" const char *gfhip_last_error(const gfhip_context *ctx) {
     return ctx ? ctx->error.c_str() : creation_error.c_str();
 }
@@ -462,6 +472,9 @@ extern "C" int gfhip_create_kernel_call(gfhip_kernel *k, const uint64_t *input_k
         size_t count = k->num_rays;
         if (indexed > count) count = indexed;
         if (input_init && input_init[i] && given > count) count = given;
+        if (input_init && input_init[i] && given < indexed) {
+            return ctx->fail("initial values of an input that index nodes read are shorter than the indexed length");
+        }
         if (ensure_buffer(ctx, input_keys[i], count, k->item.dtype, input_init ? input_init[i] : nullptr, given)) return 1;
     }
     for (size_t o = 0; o < no; o++) {
@@ -600,6 +613,44 @@ extern "C" int gfhip_run_max_complex(gfhip_kernel *k, double *value) {
         value[0] = narrow[0];
         value[1] = narrow[1];
     }
+    return 0;
+}
+
+extern "C" int gfhip_reduce_max(gfhip_context *ctx, uint64_t key, double *value) {
+    if (!ctx || !value) return 1;
+    GFHIP_TRY(ctx, hipSetDevice(ctx->device), "hipSetDevice");
+    auto found = ctx->buffers.find(key);
+    if (found == ctx->buffers.end()) return ctx->fail("unknown buffer key");
+    const buffer &b = found->second;
+    const bool wide = b.dtype == GFIR_F64 || b.dtype == GFIR_C64;
+    value[0] = value[1] = 0.0;
+    if (b.dtype == GFIR_C32 || b.dtype == GFIR_C64) {
+        if (b.count == 0) return 0;
+        gfhip::launch_max_modulus(b.pointer, b.count, wide, ctx->device_converge, ctx->stream);
+        GFHIP_TRY(ctx, hipGetLastError(), "max_modulus launch");
+        GFHIP_TRY(ctx, hipMemcpyAsync(ctx->host_converge, ctx->device_converge, 16, hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
+        GFHIP_TRY(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+        if (wide) {
+            std::memcpy(value, ctx->host_converge, 16);
+        } else {
+            float narrow[2];
+            std::memcpy(narrow, ctx->host_converge, 8);
+            value[0] = narrow[0];
+            value[1] = narrow[1];
+        }
+        return 0;
+    }
+    if (b.count == 0) {
+        value[0] = -std::numeric_limits<double>::infinity();
+        return 0;
+    }
+    GFHIP_TRY(ctx, hipMemsetAsync(ctx->device_scalar, 0, sizeof(unsigned long long), ctx->stream), "hipMemsetAsync");
+    gfhip::launch_max_reduce(b.pointer, b.count, wide, ctx->device_scalar, ctx->num_cus, ctx->stream);
+    GFHIP_TRY(ctx, hipGetLastError(), "max_reduce launch");
+    GFHIP_TRY(ctx, hipMemcpyAsync(ctx->host_scalar, ctx->device_scalar, sizeof(unsigned long long),
+                                  hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync");
+    GFHIP_TRY(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    value[0] = decode_ordered(*ctx->host_scalar, wide);
     return 0;
 }
 

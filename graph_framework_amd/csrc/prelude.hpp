@@ -19,7 +19,10 @@
 ///      non-finite numerator turns into a NaN here, where IEEE division gives an infinity);
 ///    * every stored value computed from a quotient: not zero (without v_div_fixup a quotient
 ///      with numerator -0 is +0; a zero keeps its place through every later operation, so it
-///      can only be seen in a stored zero — or in a division by it, which the first check sees);
+///      can only be seen in a stored zero — or in a division by it, which the first check sees —
+///      or by a pow node, which maps -0 and +0 to different infinities or zeros when its exponent is
+///      an odd integer: the base of every pow node that comes from a quotient is checked for zero as
+///      well, unless its exponent is a constant that is not an odd integer; codegen.hpp, GFIR_POW);
 ///    * `checked` mode only: every numerator is zero or |n| >= 2^-450, so that neither the
 ///      residual nor the quotient can be subnormal.
 ///  What the default mode leaves unchecked in fp64, and `checked` closes at 1.5 vector instructions
@@ -51,7 +54,8 @@ namespace gfhip {
 
 //  v_div_fixup only acts on special operands.  With the checks above (finite non-zero
 //  denominators, finite results, no stored zero that came from a quotient) dropping it changes
-//  nothing that can be observed, except through atan2, which tells -0 from +0: the fixup (680
+//  nothing that can be observed, except through atan2, which tells -0 from +0 (and pow with an odd
+//  integer exponent, whose base joins the zero check instead, codegen.hpp): the fixup (680
 //  of 7700 VALU instructions in the RK4 step, 8 % of its time) is kept only for items that
 //  contain an atan2 node, or on request (GFHIP_DIV_FIXUP=1).
 inline bool division_fixup(const item &it, const codegen_options &opt) {
@@ -215,6 +219,34 @@ __device__ inline gf_complex gf_erfi(const gf_complex a) {
     }
     if (isinf(z.re) && isinf(z.im)) return gf_complex(static_cast<base> (0), static_cast<base> (-0.0));
     if ((z.re + z.im)*(z.re - z.im) < -750.0) return gf_complex(static_cast<base> (0), static_cast<base> (z.im <= 0.0 ? -1.0 : 1.0));
+// Small arguments: 1 - exp(z^2) w(-z) cancels (Im erfi would keep only ~1e-16/|z| of relative accuracy).  The
+// regions are those of special::erf_complex for u = iz = (-Im z) + i(Re z) (special_functions.hpp:1534-1553):
+// |Im z| < 0.08 and |Re z| < 0.01: the Maclaurin series erfi(z) = 2/sqrt(pi) sum z^(2k+1)/(k! (2k+1)), k <= 6;
+// else |Im z| < 0.005 and |2 Re z Im z| < 0.005: the expansion of erf(x + iy) about the imaginary axis,
+//   erf(iy) + (2/sqrt pi) exp(y^2) [x (1 - x^2 (1 + 2y^2)/3 + x^4 (3 + 12y^2 + 4y^4)/30) - i x^2 y (1 - x^2 (3 + 2y^2)/6)],
+//   erf(iy) = i exp(y^2) Im w(y).
+    if (fabs(z.im) < 8.0e-2) {
+        if (fabs(z.re) < 1.0e-2) {
+            const gf_z s = gf_zmul(z, z);
+            gf_z p{0x1.f9a326f9b89b7p-14, 0.0};                                  // 2/sqrt(pi)/(6! 13)
+            const double c[6] = {0x1.c02db40040b85p-11, 0x1.565bcd0e6a53fp-8, 0x1.b82ce31288b51p-6, 0x1.ce2f21a042be2p-4,
+                                 0x1.812746b0379e7p-2, 0x1.20dd750429b6dp+0};
+            for (int k = 0; k < 6; k++) {
+                p = gf_zmul(p, s);
+                p.re += c[k];
+            }
+            const gf_z v = gf_zmul(z, p);
+            return gf_complex(static_cast<base> (v.re), static_cast<base> (v.im));
+        }
+        if (fabs(z.im) < 5.0e-3 && fabs(2.0*z.re*z.im) < 5.0e-3) {
+            const double x = -z.im, y = z.re, x2 = x*x, y2 = y*y, e = exp(y2);
+            const double wim = gf_faddeeva_upper(gf_z{y, 0.0}).im;
+            const double erf_re = e*x*(0x1.20dd750429b6dp+0 - x2*(0x1.812746b0379e7p-2 + 0x1.812746b0379e7p-1*y2)
+                                       + x2*x2*(0x1.ce2f21a042be2p-4 + y2*(0x1.ce2f21a042be2p-2 + 0x1.341f6bc02c7ecp-3*y2)));
+            const double erf_im = e*(wim - x2*y*(0x1.20dd750429b6dp+0 - x2*(0x1.20dd750429b6dp-1 + 0x1.812746b0379e7p-2*y2)));
+            return gf_complex(static_cast<base> (erf_im), static_cast<base> (-erf_re));     // -i erf(iz)
+        }
+    }
     const gf_z e = gf_zexp(gf_zmul(z, z));                                       // exp(-u^2), u = iz
     const gf_z w = gf_faddeeva(gf_z{-z.re, -z.im});                              // w(iu) = w(-z)
     const gf_z erf{1.0 - (e.re*w.re - e.im*w.im), -(e.re*w.im + e.im*w.re)};    // erf(iz)

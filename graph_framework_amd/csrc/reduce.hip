@@ -44,7 +44,10 @@ max_reduce_kernel(const T *__restrict__ base, const unsigned long long total, co
     const T *in = base + head;
     const unsigned long long n = total - head;
     if (blockIdx.x == 0 && threadIdx.x < head) {
-        m = base[threadIdx.x];
+//  The same compare as everywhere below: a NaN among the head elements is not selected
+//  (element 0 is handled by first_is_nan).
+        const T v = base[threadIdx.x];
+        m = v > m ? v : m;
     }
 //  std::max_element (cpu_context.hpp:306-322) returns element 0 if that is a NaN: every later
 //  `max < x` is false.  Elsewhere a NaN is never selected (`v > m` is false).

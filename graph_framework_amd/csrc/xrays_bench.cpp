@@ -78,6 +78,11 @@ int main(int argc, char **argv) {
         threads[i] = std::thread([&, i] () {
             time_setup.start_time(i);
             const size_t local_num_rays = batch + (extra > i ? 1 : 0);
+            size_t first = 0, last = 0;
+            if (gfhip_shard_bounds(num_rays, threads.size(), i, &first, &last) || last - first != local_num_rays) {
+                std::cerr << "shard split disagrees with xrays_bench.cpp:38-51" << std::endl;
+                exit(1);
+            }
             gf::solver::ray_solver<double> solve(directory, "", local_num_rays, i);
             solve.state["w"].assign(local_num_rays, 500.0);                 // xrays_bench.cpp:62-71
             solve.state["x"].assign(local_num_rays, 2.5);

@@ -17,15 +17,29 @@ import numpy as np
 from .xrays import shard_bounds
 
 
-def init(backend=None, device_index=None):
+#  force_collectives: run every collective below through the backend even in a one-rank group
+#  (`bench.py --gpus 1 --backend nccl --force-collectives`): the RCCL code path — dtypes, devices,
+#  API use — executes on a one-GPU box instead of for the first time on an 8-GPU node.
+_FORCE = False
+
+
+def _single():
+    import torch.distributed as dist
+    return not dist.is_initialized() or (dist.get_world_size() == 1 and not _FORCE)
+
+
+def init(backend=None, device_index=None, force_collectives=False):
     """Initialise torch.distributed from the torchrun environment.  Returns (rank, world, local_rank).
-    device_index overrides LOCAL_RANK as the CUDA device (rehearsals on a one-GPU box)."""
+    device_index overrides LOCAL_RANK as the CUDA device (rehearsals on a one-GPU box);
+    force_collectives initialises the group for one rank as well and keeps the collectives real."""
+    global _FORCE
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    _FORCE = bool(force_collectives)
+    if (world > 1 or force_collectives) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -48,7 +62,7 @@ def broadcast_bytes(data, src=0):
     """Broadcast a bytes object (a serialized work item with its tables) from `src`."""
     import torch
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single():
         return data
     device = _device()
     length = torch.tensor([len(data) if dist.get_rank() == src else 0], dtype=torch.int64, device=device)
@@ -68,7 +82,7 @@ def all_gather_shards(local, total):
     Shards are padded to the largest shard for the collective and trimmed afterwards."""
     import torch
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single():
         return local.clone()
     world = dist.get_world_size()
     sizes = [shard_bounds(total, world, r)[1] - shard_bounds(total, world, r)[0] for r in range(world)]
@@ -84,7 +98,7 @@ def max_over_ranks(value):
     """MAX all-reduce of a python float (timing)."""
     import torch
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single():
         return value
     t = torch.tensor([value], dtype=torch.float64, device=_device())
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -93,5 +107,5 @@ def max_over_ranks(value):
 
 def barrier():
     import torch.distributed as dist
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if not _single():
         dist.barrier()

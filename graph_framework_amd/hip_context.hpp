@@ -17,8 +17,8 @@
 ///
 ///  All eight flavours of the reference are served: float, double and their
 ///  complex forms, with and without the SAFE_MATH guards (cpu_context.hpp:530-547,
-///  arithmetic.hpp:2534-2557), and kernels with a random state (random.hpp).  Only
-///  erfi nodes (special_functions.hpp) are not lowered.
+///  arithmetic.hpp:2534-2557), kernels with a random state (random.hpp) and erfi
+///  nodes (math.hpp:1440; csrc/prelude.hpp gf_erfi).
 //------------------------------------------------------------------------------
 #ifndef hip_context_h
 #define hip_context_h
@@ -72,13 +72,33 @@ namespace gpu {
             gfhip_kernel *kernel;
             graph::input_nodes<T, SAFE_MATH> inputs;        ///< distinct input variables, first-seen order
             graph::output_nodes<T, SAFE_MATH> outputs;      ///< outputs the kernel stores
+///  Expression node -> the variable whose buffer holds its value after the kernel: a setter's
+///  expression is stored into the setter's variable and, listed as an output as well, not again.
+            std::map<graph::leaf_node<T, SAFE_MATH> *, graph::leaf_node<T, SAFE_MATH> *> held_by;
         };
         std::map<std::string, bound_kernel> kernels;
-///  Kernel whose last stored output is a node (for create_max_call).
-        std::map<graph::leaf_node<T, SAFE_MATH> *, gfhip_kernel *> reductions;
+
+///  The closure create_kernel_call returns.  A type of its own, so that create_max_call can tell
+///  from its `run` argument (std::function::target) which kernel it is asked to run.
+        struct kernel_call {
+            hip_context *self;
+            gfhip_kernel *kernel;
+            const bound_kernel *bound;
+            void operator()() const {
+                self->check(gfhip_run(kernel, 1), "gfhip_run");
+            }
+        };
 
         static uint64_t key(graph::leaf_node<T, SAFE_MATH> *node) {
             return static_cast<uint64_t> (reinterpret_cast<uintptr_t> (node));
+        }
+
+        static T from_parts(const double *value) {
+            if constexpr (jit::complex_scalar<T>) {
+                return T(static_cast<typename T::value_type> (value[0]), static_cast<typename T::value_type> (value[1]));
+            } else {
+                return static_cast<T> (value[0]);
+            }
         }
 
         void check(const int status, const char *what) const {
@@ -132,7 +152,7 @@ namespace gpu {
         hip_context &operator=(const hip_context &) = delete;
         hip_context(hip_context &&other) noexcept :
         context(other.context), pending(std::move(other.pending)), kernels(std::move(other.kernels)),
-        reductions(std::move(other.reductions)), remaining_const_memory(other.remaining_const_memory) {
+        remaining_const_memory(other.remaining_const_memory) {
             other.context = nullptr;
         }
         hip_context &operator=(hip_context &&other) noexcept {
@@ -142,7 +162,6 @@ namespace gpu {
                 other.context = nullptr;
                 pending = std::move(other.pending);
                 kernels = std::move(other.kernels);
-                reductions = std::move(other.reductions);
                 remaining_const_memory = other.remaining_const_memory;
             }
             return *this;
@@ -230,7 +249,11 @@ namespace gpu {
                 const std::string text = source_buffer.str();
                 serialize.kernel_text = &text;
                 item.gfir = serialize(item.name, item.inputs, kept, stores);
-                kernels[item.name] = bound_kernel{nullptr, item.inputs, kept};
+                bound_kernel bound{nullptr, item.inputs, kept, {}};
+                for (auto &[out, in] : stores) {
+                    bound.held_by[out.get()] = in.get();
+                }
+                kernels[item.name] = bound;
             }
         }
 
@@ -312,13 +335,7 @@ namespace gpu {
             for (auto &output : outputs) {
                 check(gfhip_allocate_buffer(context, key(output.get()), num_rays, dtype), "gfhip_allocate_buffer");
             }
-            if (!bound.outputs.empty()) {
-                reductions[bound.outputs.back().get()] = kernel;
-            }
-
-            return [this, kernel] () mutable {
-                check(gfhip_run(kernel, 1), "gfhip_run");
-            };
+            return kernel_call{this, kernel, &bound};
         }
 
 //------------------------------------------------------------------------------
@@ -326,21 +343,42 @@ namespace gpu {
 //------------------------------------------------------------------------------
         std::function<T(void)> create_max_call(graph::shared_leaf<T, SAFE_MATH> &argument,
                                                std::function<void(void)> run) {
-            (void)run;
-            auto found = reductions.find(argument.get());
-            if (found == reductions.end()) {
-                std::cerr << "hip_context: create_max_call needs the last stored output of a kernel." << std::endl;
-                exit(-1);
-            }
-            gfhip_kernel *kernel = found->second;
-            return [this, kernel] () mutable {
-                double value[2];
-                check(gfhip_run_max_complex(kernel, value), "gfhip_run_max");
-                if constexpr (jit::complex_scalar<T>) {
-                    return T(static_cast<typename T::value_type> (value[0]), static_cast<typename T::value_type> (value[1]));
-                } else {
-                    return static_cast<T> (value[0]);
+//  The contract (jit.hpp:274-277; cuda_context.hpp:540-576, cpu_context.hpp:306-322): run `run`,
+//  then reduce the buffer that holds `argument`.  `run` is normally the closure the preceding
+//  create_kernel_call returned (workflow.hpp:172): when it is, and `argument` is the LAST output
+//  that kernel stores, the max is folded into the kernel's own launch (gfhip_run_max).  In every
+//  other case — a foreign `run`, an argument that is a variable, that a setter stores or that is
+//  not the last output — `run` runs as given and the buffer holding `argument` is reduced.
+            const kernel_call *call = run.template target<kernel_call> ();
+            graph::leaf_node<T, SAFE_MATH> *holder = argument.get();
+            if (call && call->self == this) {
+                auto held = call->bound->held_by.find(holder);
+                if (held != call->bound->held_by.end()) {
+                    holder = held->second;
                 }
+                if (!call->bound->outputs.empty() && call->bound->outputs.back().get() == argument.get()) {
+                    gfhip_kernel *kernel = call->kernel;
+                    return [this, kernel] () mutable {
+                        double value[2];
+                        check(gfhip_run_max_complex(kernel, value), "gfhip_run_max");
+                        return from_parts(value);
+                    };
+                }
+            } else {
+                for (auto &[name, bound] : kernels) {
+                    auto held = bound.held_by.find(holder);
+                    if (held != bound.held_by.end()) {
+                        holder = held->second;
+                        break;
+                    }
+                }
+            }
+            const uint64_t buffer_key = key(holder);
+            return [this, run, buffer_key] () mutable {
+                run();
+                double value[2];
+                check(gfhip_reduce_max(context, buffer_key, value), "gfhip_reduce_max");
+                return from_parts(value);
             };
         }
 

@@ -44,6 +44,13 @@ int gfhip_max_concurrency(void);
 /* Replaces  static std::string device_type()  (cuda_context.hpp:130-132, jit.hpp:92). */
 const char *gfhip_device_type(void);
 
+/* Host side, no device: the contiguous split every reference driver applies to its ensemble, one
+ * shard per device thread:  batch = total/shards, extra = total%shards, shard `index` holds
+ * batch + (extra > index ? 1 : 0) elements  (graph_benchmark/xrays_bench.cpp:38-51,
+ * graph_driver/xrays.cpp:423-432, graph_korc/xkorc.cpp:20-25).  Writes [*begin, *end) of the
+ * shard; returns 1 if shards == 0 or index >= shards. */
+int gfhip_shard_bounds(size_t total, size_t shards, size_t index, size_t *begin, size_t *end);
+
 /* Bind device `index`.  `stream` is a hipStream_t to launch on, or NULL to
  * create a private one.  Replaces the context constructor  ctx(const size_t index)
  * (cuda_context.hpp:137-148, jit.hpp:101).  Returns NULL on failure
@@ -95,6 +102,14 @@ int gfhip_run_max(gfhip_kernel *kernel, double *max_value);
  * the element of largest modulus of the last output, the first of equals, as
  * cpu_context.hpp:314-318 selects it (std::max_element on std::abs). */
 int gfhip_run_max_complex(gfhip_kernel *kernel, double *value);
+
+/* Reduce a BUFFER, whatever wrote it: value[0] (+ i value[1] for a complex buffer) = the max of its
+ * elements as cpu_context takes it (std::max_element, cpu_context.hpp:306-322: a NaN only if it is
+ * element 0; complex: the element of largest modulus, the first of equals), after everything queued on
+ * the context's stream; synchronises.  This is the general form of  create_max_call(arg, run)
+ * (jit.hpp:274-277): the caller runs `run` and then reduces `arg`'s buffer, which need not be the last
+ * output of the kernel that `run` launches. */
+int gfhip_reduce_max(gfhip_context *ctx, uint64_t key, double *value);
 
 /* The loop of workflow::converge_item::run (workflow.hpp:179-205) around
  * gfhip_run_max: repeat until |max| <= tol, or max stalls against the previous

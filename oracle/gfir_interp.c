@@ -327,6 +327,37 @@ void gfi_erfi(const double re, const double im, double *out) {
     if (isinf(re) && isinf(im)) { out[0] = 0.0; out[1] = -0.0; return; }
     if ((re + im)*(re - im) < -750.0) { out[0] = 0.0; out[1] = im <= 0.0 ? -1.0 : 1.0; return; }
     const gfi_z z = {re, im}, mirrored = {-re, -im};
+/*  Small arguments, in the regions where special::erf_complex leaves its general formula
+ *  (special_functions.hpp:1534-1553, u = iz): the Maclaurin series of erfi for |Im z| < 0.08, |Re z| < 0.01;
+ *  the expansion of erf(x + iy) about the imaginary axis for |Im z| < 0.005, |2 Re z Im z| < 0.005
+ *  (formulas: graph_framework_amd/csrc/prelude.hpp, gf_erfi). */
+    if (fabs(im) < 8.0e-2) {
+        if (fabs(re) < 1.0e-2) {
+            static const double c[6] = {0x1.c02db40040b85p-11, 0x1.565bcd0e6a53fp-8, 0x1.b82ce31288b51p-6,
+                                        0x1.ce2f21a042be2p-4, 0x1.812746b0379e7p-2, 0x1.20dd750429b6dp+0};
+            const gfi_z s = gfi_zmul(z, z);
+            gfi_z p = {0x1.f9a326f9b89b7p-14, 0.0};
+            for (int k = 0; k < 6; k++) {
+                p = gfi_zmul(p, s);
+                p.re += c[k];
+            }
+            const gfi_z v = gfi_zmul(z, p);
+            out[0] = v.re;
+            out[1] = v.im;
+            return;
+        }
+        if (fabs(im) < 5.0e-3 && fabs(2.0*re*im) < 5.0e-3) {
+            const double x = -im, y = re, x2 = x*x, y2 = y*y, e = exp(y2);
+            const gfi_z on_axis = {y, 0.0};
+            const double wim = gfi_faddeeva_upper(on_axis).im;
+            const double erf_re = e*x*(0x1.20dd750429b6dp+0 - x2*(0x1.812746b0379e7p-2 + 0x1.812746b0379e7p-1*y2)
+                                       + x2*x2*(0x1.ce2f21a042be2p-4 + y2*(0x1.ce2f21a042be2p-2 + 0x1.341f6bc02c7ecp-3*y2)));
+            const double erf_im = e*(wim - x2*y*(0x1.20dd750429b6dp+0 - x2*(0x1.20dd750429b6dp-1 + 0x1.812746b0379e7p-2*y2)));
+            out[0] = erf_im;
+            out[1] = -erf_re;
+            return;
+        }
+    }
     const gfi_z e = gfi_zexp(gfi_zmul(z, z)), w = gfi_faddeeva(mirrored);
     const double erf_re = 1.0 - (e.re*w.re - e.im*w.im), erf_im = -(e.re*w.im + e.im*w.re);
     out[0] = erf_im;

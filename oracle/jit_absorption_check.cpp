@@ -10,7 +10,16 @@
 // of ref_builders.hpp; the values are checked against the tape (std::complex arithmetic, the reference's
 // special::erfi) with the tolerances of tests/test_oracle.py.
 //
-//   jit_absorption_check <tables.bin> <in: kamp kx ky kz x y z t w (real columns)>
+//   jit_absorption_check <tables.bin> <in: kamp kx ky kz x y z t w (real columns)> [device-stalls]
+//
+// root_finder's Newton loop (tolerance 1e-30) ends on stagnation, which last-bit noise of the complex
+// product and quotient decides: on some records it does not end within 1000 iterations — on the
+// reference graph layer's own tape for records 3 and 13 of the golden trajectories, on other records
+// in other arithmetics.  workflow::converge_item::run then asserts (workflow.hpp:197, debug builds abort:
+// reference behaviour) or, in a release build (-DNDEBUG, as this program is built), reports "Workitem
+// failed to converge" on stderr (:198-204) and goes on.  The roots are compared only where BOTH loops
+// ended; `device-stalls` (any third argument) says that the device's loop is known not to end on this
+// record (tests/test_gpu_workflows.py knows it from the same kernels under gfhip_converge).
 // ---------------------------------------------------------------------------
 #include <complex>
 
@@ -45,10 +54,11 @@ static void load(ITEMS &items, const std::vector<std::vector<double>> &cols) {
 }
 
 int main(int argc, char **argv) {
-    if (argc != 3) {
-        fprintf(stderr, "usage: jit_absorption_check <tables.bin> <in>\n");
+    if (argc != 3 && argc != 4) {
+        fprintf(stderr, "usage: jit_absorption_check <tables.bin> <in> [device-stalls]\n");
         return 2;
     }
+    const bool device_stalls = argc == 4;
     const raw_tables raw(argv[1]);
     size_t n;
     const auto cols = read_columns(argv[2], 9, n);
@@ -149,11 +159,16 @@ int main(int argc, char **argv) {
         for (size_t i = 0; i < n; i++) {
             worst = std::max(worst, std::abs(got[i] - columns[0][i])/std::abs(columns[0][i]));
         }
-        const bool converged = iterations <= 1000;
-        const bool ok = !converged || worst <= 1.0e-12;
-        printf("root_finder over workflow::manager + solver::newton: %zu rays, tape %zu iterations%s, worst "
-               "|difference|/|kamp| %.3g: %s\n", n, iterations, converged ? "" : " (not converged: not compared)",
-               worst, ok ? "ok" : "FAILED");
+//  On the last golden record the host's std::complex arithmetic makes ray 0 a NaN in the first pass; the max is
+//  then that NaN, every test of the loop is false and all rays keep their first iterate: nothing to compare.
+        bool tape_nan = false;
+        for (size_t i = 0; i < n; i++) tape_nan = tape_nan || columns[0][i] != columns[0][i];
+        const bool converged = iterations <= 1000 && !tape_nan;
+        if (tape_nan) printf("root_finder: the tape ends in NaN after %zu iteration(s)\n", iterations);
+        const bool ok = !converged || device_stalls || worst <= 1.0e-12;
+        printf("root_finder over workflow::manager + solver::newton: %zu rays, tape %zu iterations%s%s, worst "
+               "|difference|/|kamp| %.3g: %s\n", n, iterations, converged ? "" : " (tape not converged: not compared)",
+               device_stalls ? " (device not converged: not compared)" : "", worst, ok ? "ok" : "FAILED");
         failures += !ok;
     }
     return failures ? 1 : 0;

@@ -23,6 +23,28 @@ def test_shard_bounds_match_reference_split():
         assert begin == total
 
 
+def test_c_abi_shard_split_is_the_reference_split():
+    """gfhip_shard_bounds (include/gf_hip.h) is what the C++ drivers split with (csrc/korc_push.cpp:
+    graph_korc/xkorc.cpp:20-25; csrc/xrays_bench.cpp): the same shards as xrays.shard_bounds, which
+    the ranks of bench.py use, for every thread of every case, ragged and empty shards included."""
+    import ctypes
+    from graph_framework_amd import _lib
+    from graph_framework_amd.xrays import shard_bounds
+    lib = _lib.load()
+    begin, end = ctypes.c_size_t(), ctypes.c_size_t()
+    for total, shards in ((10000000, 8), (10000000, 3), (7, 8), (0, 4), (1, 1), (1000003, 6), (1000, 2)):
+        covered = 0
+        for i in range(shards):
+            assert lib.gfhip_shard_bounds(total, shards, i, ctypes.byref(begin), ctypes.byref(end)) == 0
+            assert (begin.value, end.value) == shard_bounds(total, shards, i)
+            assert end.value - begin.value == total//shards + (1 if total % shards > i else 0)      # xkorc.cpp:24
+            assert begin.value == covered
+            covered = end.value
+        assert covered == total
+    assert lib.gfhip_shard_bounds(10, 0, 0, ctypes.byref(begin), ctypes.byref(end)) == 1
+    assert lib.gfhip_shard_bounds(10, 2, 2, ctypes.byref(begin), ctypes.byref(end)) == 1
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -92,6 +114,30 @@ def test_bench_starts_its_own_ranks():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 3 and line["total_rays"] == 1000003 and line["launcher"] == "bench.py"
     assert line["gathered_elements"] == 8*1000003 and line["slowest_rank"] == 2.0 and line["item_bytes"] > 100000
+
+
+def test_bench_korc_leg_starts_its_own_ranks():
+    """BASELINE configs[4] over N ranks (`--workload korc`): the four xkorc work items are broadcast
+    from rank 0 and arrive byte-identical, the particles are split as graph_korc/xkorc.cpp:16-25
+    splits them over its device threads, the seven fp32 particle arrays are all-gathered."""
+    import json
+    out = _run_bench(["--gpus", "2", "--rehearse-cpu", "--workload", "korc", "--total-rays", "10000001"])
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line["workload"] == "korc" and line["n_gpus"] == 2 and line["items"] == 4
+    assert line["gathered_elements"] == 7*10000001 and line["item_bytes"] > 1000000
+
+
+def test_one_rank_group_runs_real_collectives():
+    """--force-collectives: a ONE-rank process group whose broadcast / all-gather / max run through
+    the backend (gloo here; `--backend nccl` on the GPU box is tests/test_gpu_bench.py)."""
+    import json
+    out = _run_bench(["--gpus", "1", "--rehearse-cpu", "--force-collectives", "--total-rays", "1001"])
+    assert out.returncode == 0, out.stdout + out.stderr
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert line["n_gpus"] == 1 and line["gathered_elements"] == 8*1001
 
 
 def test_bench_launcher_reports_a_failed_rank():

@@ -146,3 +146,41 @@ def test_fp32_quotients_are_ieee_for_random_bit_patterns():
         want = n/d
     assert _same(got, want), np.flatnonzero(_bits(got) != _bits(want))[:8]
     assert np.isnan(want).sum() > 1000 and (np.abs(want) < np.finfo(np.float32).tiny).sum() > 1000   # the sample does reach the edges
+
+
+@pytest.mark.parametrize("exponent", [-1.0, 3.0, -2.0, 1.5])
+def test_pow_of_a_quotient_sees_the_ieee_sign_of_zero(exponent):
+    """pow tells -0 from +0 when its exponent is an odd integer.  1 + exp(-pow(n/d, -1)) is 1 on a
+    quotient of +0 and inf on -0 — a finite, non-zero stored value that no other check would catch — so a pow
+    base that comes from a shared-reciprocal quotient joins the zero check (codegen.hpp, GFIR_POW) unless its
+    exponent is a constant that is not an odd integer.  Device against oracle, bit for bit, zeros of both signs
+    among the numerators."""
+    from graph_framework_amd import Context
+    from test_gpu_generic import Item, INPUT, DIV, POW, EXP, SUB, ADD
+    it = Item("f64", False, ["n", "d"], name="pow_zero_sign")
+    n, d = it.emit(INPUT, a=0), it.emit(INPUT, a=1)
+    q = it.emit(DIV, n, d)
+    p = it.emit(POW, q, it.constant(exponent))
+    one, zero = it.constant(1.0), it.constant(0.0)
+    observed = it.emit(ADD, one, it.emit(EXP, it.emit(SUB, zero, p)))
+    blob = it.blob([observed], [])            # the power itself is NOT stored: its infinity would fail the finite check
+    rng = np.random.default_rng(23)
+    rays = 1024
+    num = rng.uniform(-2.0, 2.0, rays)
+    den = rng.uniform(0.5, 3.0, rays)*rng.choice([-1.0, 1.0], rays)
+    num[::5] = 0.0
+    num[2::7] = -0.0
+    context = Context(0)
+    kernel = context.add_kernel(blob, rays)
+    context.compile()
+    kernel.create_kernel_call(["n", "d"], ["observed"], [num, den])
+    kernel.run(1)
+    context.wait()
+    got = context.copy_to_host("observed", np.empty(rays))
+    context.close()
+    with np.errstate(all="ignore"):
+        want, _ = gfir.Item(blob).run([num.copy(), den.copy()])
+    assert _same(got, want[0])
+    if exponent == -1.0:
+        negative_zero = np.signbit(num/den) & (num/den == 0.0)
+        assert negative_zero.sum() > 50 and np.isinf(want[0][negative_zero]).all()

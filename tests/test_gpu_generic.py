@@ -255,3 +255,101 @@ def test_erfi_branches_on_the_device():
     np.testing.assert_allclose(got.imag[8:11], want.imag[8:11], rtol=4.0e-16, atol=0.0)
     assert np.array_equal(got[11:14], want[11:14])
     assert abs(got[14].real - want[14].real) <= 1.0e-12*abs(want[14].real)        # off the axis: the general formula
+
+
+def test_erfi_small_arguments_on_the_device():
+    """off the axes and for small |z| the device leaves the cancelling general formula for the
+    series special::erf_complex uses there (special_functions.hpp:1534-1553; prelude.hpp gf_erfi).  Each
+    part of erfi within 1e-14 relative of the exactly summed power series and of the oracle, in both
+    series regions (the device's exp and the Weideman sum are its own libm's)."""
+    from graph_framework_amd import Context
+    from test_oracle import _erfi_series_exact
+    it = Item("c64", False, ["z"], name="erfi_small")
+    blob = it.blob([it.emit(ERFI, it.emit(INPUT, a=0))], [])
+    points = []
+    for scale in (1.0e-8, 1.0e-5, 1.0e-3, 9.0e-3):
+        points += [complex(scale, scale), complex(scale, -3.0*scale), complex(-scale, 7.9*scale), complex(-0.3*scale, -scale)]
+    for re in (1.1e-2, 5.0e-2, 0.2, 0.45, 2.4):
+        for im in (1.0e-9, -1.0e-6, 1.0e-4, -4.9e-3 if re < 1.0 else -1.0e-3):
+            points += [complex(re, im), complex(-re, im)]
+    z = np.array(points, dtype=np.complex128)
+    context = Context(0)
+    kernel = context.add_kernel(blob, z.size)
+    context.compile()
+    kernel.create_kernel_call(["z"], ["erfi"], [z])
+    kernel.run(1)
+    context.wait()
+    got = context.copy_to_host("erfi", np.empty(z.size, dtype=np.complex128))
+    context.close()
+    series = np.array([_erfi_series_exact(complex(v), 90) for v in z])
+    oracle = np.array([gfir.erfi(complex(v)) for v in z])
+    for want in (series, oracle):
+        np.testing.assert_allclose(got.real, want.real, rtol=1.0e-14, atol=0.0)
+        np.testing.assert_allclose(got.imag, want.imag, rtol=1.0e-14, atol=0.0)
+
+
+def test_indexed_input_longer_than_the_ensemble():
+    """an input that index_1D nodes read keeps its own length (piecewise.hpp:1530-1575).  With 20
+    rays and a 64-element buffer the Python path used to upload only the first 20 elements; the elements
+    past the ensemble size are the ones read here.  A buffer shorter than the indexed length is refused."""
+    from graph_framework_amd import Context, GfHipError
+    it = Item("f64", False, ["b", "v"], name="long_index")
+    b = it.emit(INPUT, a=0)
+    picked = it.emit(INDEX1, b, c=1, aux=64, imm=(0.125, -1.0, 0.0, 0.0))       # v[clamp((b + 1)/0.125)]
+    blob = it.blob([it.emit(ADD, picked, b)], [])
+    rays = 20
+    position = np.linspace(1.6, 6.9, rays)                                      # indices 20 .. 63: all past the ensemble size
+    v = np.arange(64, dtype=np.float64)*3.0 + 0.5
+    context = Context(0)
+    kernel = context.add_kernel(blob, rays)
+    context.compile()
+    kernel.create_kernel_call(["b", "v"], ["picked"], [position, v])
+    kernel.run(1)
+    context.wait()
+    got = context.copy_to_host("picked", np.empty(rays))
+    index = np.clip(((position + 1.0)/0.125), 0, 63).astype(np.int64)
+    assert index.min() >= rays and index.max() == 63
+    assert np.array_equal(got, v[index] + position)
+    oracle_out, _ = gfir.Item(blob).run([position.copy(), v.copy()])
+    assert np.array_equal(got, oracle_out[0])
+    assert context.buffer_info("v")[0] == 64
+    other = Context(0)
+    short = other.add_kernel(blob, rays)
+    other.compile()
+    with pytest.raises(GfHipError):
+        short.create_kernel_call(["b", "v"], ["picked"], [position, v[:32]])
+    context.close()
+    other.close()
+
+
+def test_separate_max_reduction_skips_a_nan_in_its_alignment_head():
+    """reduce.hip folds the elements in front of the first 16-byte boundary with the same `v > m`
+    as the rest, so a NaN at element 1 or 2 is skipped as std::max_element skips it (cpu_context.hpp:306-322);
+    only a NaN at element 0 is the maximum.  An item of > 1500 nodes has no `<name>_max` entry and takes the
+    separate reduction kernel; the fp32 output is a tensor that starts 4 bytes past a 16-byte boundary."""
+    import torch
+    from graph_framework_amd import Context
+    it = Item("f32", False, ["a"], name="long_chain")
+    node, zero = it.emit(INPUT, a=0), it.constant(0.0)
+    for _ in range(1600):
+        node = it.emit(ADD, node, zero)
+    blob = it.blob([node], [])
+    n = 5000
+    rng = np.random.default_rng(3)
+    for nan_at, expect_nan in ((1, False), (2, False), (0, True)):
+        a = rng.uniform(-4.0, 3.0, n).astype(np.float32)
+        a[nan_at] = np.nan
+        out = torch.zeros(n + 1, dtype=torch.float32, device="cuda")
+        context = Context(0, torch.cuda.current_stream().cuda_stream)
+        context.set_buffer("o", out[1:])
+        kernel = context.add_kernel(blob, n)
+        context.compile()
+        assert kernel.info().num_instructions > 1500
+        kernel.create_kernel_call(["a"], ["o"], [a])
+        value = kernel.run_max()
+        torch.cuda.synchronize()
+        if expect_nan:
+            assert np.isnan(value)
+        else:
+            assert np.float32(value) == np.nanmax(a), (nan_at, value)
+        context.close()

@@ -344,15 +344,22 @@ def test_power_item_on_the_oracle_matches_the_reference_bit_for_bit():
 def root_finder_matches(got, want, iterations_got, iterations_want):
     """absorption::root_finder against another arithmetic (std::complex on the host, the device's libm):
     the Newton loop stops on stagnation at 1e-30, so iteration counts and the noise below 1e-12 |kamp|
-    (imaginary parts of 1e-100 next to a real part of 200) are not comparable; the root is.  Records on
-    which either side runs out of iterations, or the reference graph itself ends in NaN, are skipped."""
+    (imaginary parts of 1e-100 next to a real part of 200) are not comparable; the root is.  A record on
+    which either side runs out of its 1000 iterations has no root to compare (the loop's last iterate is
+    whatever the stagnation noise left): it must be one whose iteration count says so — nothing else is
+    left out — and the iterate must still be within 1e-6 |kamp| of the other side's.
+    One more record is not comparable, and is recognised by what makes it so: on the last record the host's
+    std::complex arithmetic turns ray 0 into NaN in the first pass, the shard's max is that NaN, every test of
+    the loop is false and ALL rays of the shard keep their first Newton iterate (iteration count 1)."""
     compared = 0
     for r in range(want.shape[0]):
-        if iterations_got[r] > 1000 or iterations_want[r] > 1000 or not np.isfinite(want[r]).all():
-            continue
         assert np.isfinite(got[r]).all(), r
-        assert (np.abs(got[r] - want[r]) <= 1.0e-12*np.abs(want[r])).all(), (r, got[r], want[r])
-        compared += 1
+        if not np.isfinite(want[r]).all():
+            assert iterations_want[r] == 1 and iterations_got[r] > 1, r
+            continue
+        bound = 1.0e-6 if iterations_got[r] > 1000 or iterations_want[r] > 1000 else 1.0e-12
+        assert (np.abs(got[r] - want[r]) <= bound*np.abs(want[r])).all(), (r, got[r], want[r])
+        compared += bound == 1.0e-12
     return compared
 
 
@@ -421,3 +428,48 @@ def test_erfi_branches_taken_before_the_general_formula():
         assert gfir.erfi(complex(-x, 0.0)).real == -value.real
     assert gfir.erfi(complex(27.0, 0.0)).real == 1.7976931348623157e308 and gfir.erfi(complex(-27.0, -0.0)).real == -1.7976931348623157e308
     assert gfir.erfi(complex(1.0, 28.0)) == complex(0.0, 1.0) and gfir.erfi(complex(1.0, -28.0)) == complex(0.0, -1.0)
+
+
+def _erfi_series_exact(z, terms=60):
+    """erfi(z) = 2/sqrt(pi) sum z^(2k+1)/(k! (2k+1)) summed in exact rational arithmetic on the
+    (exactly representable) parts of z, rounded once and scaled by 2/sqrt(pi)."""
+    import math
+    from fractions import Fraction
+    a, b = Fraction(z.real), Fraction(z.imag)
+    sq_re, sq_im = a*a - b*b, 2*a*b                                  # z^2
+    pr, pi_ = a, b                                                   # z^(2k+1)
+    sum_re = sum_im = Fraction(0)
+    for k in range(terms):
+        weight = Fraction(1, math.factorial(k)*(2*k + 1))
+        sum_re += pr*weight
+        sum_im += pi_*weight
+        pr, pi_ = pr*sq_re - pi_*sq_im, pr*sq_im + pi_*sq_re
+    scale = Fraction(2)/Fraction(math.sqrt(math.pi))                 # the double nearest sqrt(pi): 1 ulp
+    return complex(float(sum_re*scale), float(sum_im*scale))
+
+
+def test_erfi_keeps_its_relative_accuracy_for_small_arguments():
+    """off the axes the general formula 1 - exp(z^2) w(-z) loses Im erfi(z) to cancellation for
+    small |z| (7e-13 at 1e-3(1 + i), 2e-8 at 1e-8(1 + i)); the reference leaves it there for series
+    (special_functions.hpp:1534-1553), and so do prelude.hpp / gfir_interp.c now.  Both parts of erfi are
+    held to the exactly summed power series at 4e-15 relative in each part, in both series regions, at
+    their edges, in all four quadrants."""
+    points = []
+    for scale in (1.0e-8, 1.0e-5, 1.0e-3, 9.0e-3):                   # Maclaurin region |Re| < 0.01, |Im| < 0.08
+        points += [complex(scale, scale), complex(scale, -3.0*scale), complex(-scale, 7.9*scale), complex(-0.3*scale, -scale)]
+    points += [complex(9.9e-3, 7.9e-2), complex(-1.0e-4, 7.0e-2)]
+    for re in (1.1e-2, 5.0e-2, 0.2, 0.45):                           # near-axis region |Im| < 0.005, |2 Re Im| < 0.005
+        for im in (1.0e-9, -1.0e-6, 1.0e-4, -4.9e-3):
+            points += [complex(re, im), complex(-re, im)]
+    points += [complex(2.4, 1.0e-3), complex(-2.4, -1.0e-5)]
+    worst = 0.0
+    for z in points:
+        got, want = gfir.erfi(z), _erfi_series_exact(z, 90)
+        for g, w in ((got.real, want.real), (got.imag, want.imag)):
+            assert abs(g - w) <= 4.0e-15*abs(w), (z, got, want)
+            worst = max(worst, abs(g - w)/abs(w))
+    assert worst > 0.0                                               # it is a floating-point evaluation, not the series itself
+#  just outside the regions the general formula is back, and still fine at 1e-13 there
+    for z in (complex(1.1e-2, 6.0e-3), complex(0.3, 9.0e-3), complex(1.0e-3, 9.0e-2)):
+        got, want = gfir.erfi(z), _erfi_series_exact(z, 90)
+        assert abs(got.real - want.real) <= 1.0e-13*abs(want.real) and abs(got.imag - want.imag) <= 1.0e-13*abs(want.imag), z
