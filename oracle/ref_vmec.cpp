@@ -85,6 +85,52 @@ int main(int argc, char **argv) {
         write_columns(argv[5], outs);
         return 0;
     }
+//  The (cold_plasma x rk4 x vmec) combination of graph_driver/xrays.cpp:382: Newton init of one unknown,
+//  then RK4 steps in flux coordinates (x, y, z = s, u, v; k = k_s e^s + k_u e^u + k_v e^v), as cmd_trace of
+//  ref_driver.cpp does on EFIT.  out: per saved step 9 columns (8 state + residual); with `dir` the two items
+//  are written as GFIR (vmec<modes>_loss_kernel_<unknown>, vmec<modes>_solver_kernel).
+    if (cmd == "trace" && argc >= 10) {
+        vmec<T> eq(raw, modes);
+        size_t n;
+        auto cols = read_columns(argv[4], 8, n);
+        const double dt = atof(argv[6]);
+        const size_t num_steps = strtoull(argv[7], nullptr, 10), save_every = strtoull(argv[8], nullptr, 10);
+        const int newton_var = atoi(argv[9]);
+        ray_variables<T> v;
+        double t0 = seconds();
+        dispersion_interface<T> D(v.w, v.kx, v.ky, v.kz, v.x, v.y, v.z, eq);
+        std::vector<T> residual(n, 0);
+        std::vector<T *> in;
+        for (auto &c : cols) in.push_back(c.data());
+        const char *unknown_names[7] = {"w", "kx", "ky", "kz", "x", "y", "z"};
+        const std::string prefix = "vmec" + std::to_string(modes) + "_";
+        if (newton_var >= 0) {
+            work_item<T> loss = make_loss_kernel(v, D.D, newton_var, static_cast<T> (1.0));
+            fprintf(stderr, "loss_kernel ");
+            loss.code.print_counts(stderr);
+            if (argc > 10) loss.write_gfir("loss_kernel", (std::string(argv[10]) + "/" + prefix + "loss_kernel_" + unknown_names[newton_var] + "_f64.gfir").c_str());
+            T last;
+            const size_t it = converge(loss, n, in, residual.data(), static_cast<T> (1.0E-30), 1000, &last);
+            fprintf(stderr, "{\"newton_iterations\": %zu, \"newton_last_max\": %.17g}\n", it, static_cast<double> (last));
+        }
+        work_item<T> solver = make_solver_kernel(v, eq, static_cast<T> (dt), D);
+        fprintf(stderr, "solver_kernel (built in %.1f s) ", seconds() - t0);
+        solver.code.print_counts(stderr);
+        if (argc > 10) solver.write_gfir("solver_kernel", (std::string(argv[10]) + "/" + prefix + "solver_kernel_f64.gfir").c_str());
+        std::vector<std::vector<double>> record;
+        auto save = [&] () {
+            for (size_t c = 0; c < 8; c++) record.push_back(cols[c]);
+            record.emplace_back(residual.begin(), residual.end());
+        };
+        save();
+        for (size_t step = 1; step <= num_steps; step++) {
+            solver.run(n, in, {residual.data()});
+            if (save_every && (step%save_every == 0 || step == num_steps)) save();
+        }
+        if (!save_every) save();
+        write_columns(argv[5], record);
+        return 0;
+    }
     fprintf(stderr, "bad command\n");
     return 2;
 }

@@ -5,6 +5,8 @@ graph_tests/vmec.nc: 86 Fourier modes, 198 flux surfaces) from the reference's o
 
     graph_framework_amd/workloads/vmec_field_kernel_f64.gfir   inputs (s, u, v); outputs B (3), x, y, z, ne, te
     tests/golden/vmec_golden.npz
+    tests/golden/vmec_tables.npz       the spline tables of graph_tests/vmec.nc as plain arrays (a data fixture, like
+                                       efit_tables.npz): what the independent numpy evaluation of tests/test_oracle.py reads
 
 Only the field evaluation: the ray equations on this equilibrium are not part of the fixtures, because
 the reference's reducer does not get through d(cold_plasma D)/ds on the VMEC graph.
@@ -48,7 +50,20 @@ def write_vmec(path, source="/root/reference/graph_tests/vmec.nc"):
     return nummn
 
 
+def write_tables_npz(path, source="/root/reference/graph_tests/vmec.nc"):
+    f = H5File(source)
+    out = {k: float(f.read(k)) for k in ("sminh", "sminf", "ds", "dphi", "signj")}
+    for k in range(4):
+        out["chi_c%d" % k] = f.read("chi_c%d" % k)
+        for quantity in ("rmnc", "zmns", "lmns"):
+            out["%s_c%d" % (quantity, k)] = f.read("%s_c%d" % (quantity, k))
+    out["xm"], out["xn"] = f.read("xm"), f.read("xn")
+    f.close()
+    np.savez_compressed(path, **out)
+
+
 def main():
+    write_tables_npz(os.path.join(HERE, "vmec_tables.npz"))
     with tempfile.TemporaryDirectory() as tmp:
         tables = os.path.join(tmp, "vmec.bin")
         modes = write_vmec(tables)
