@@ -25,7 +25,8 @@ class KernelInfo(ctypes.Structure):
                 ("vgprs", ctypes.c_uint32), ("agprs", ctypes.c_uint32), ("sgprs", ctypes.c_uint32),
                 ("lds_bytes", ctypes.c_uint32), ("scratch_bytes", ctypes.c_uint32),
                 ("block_size", ctypes.c_uint32), ("grid_size", ctypes.c_uint32),
-                ("from_cache", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
+                ("from_cache", ctypes.c_uint32), ("segments", ctypes.c_uint32),
+                ("converge_batch", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
                 ("source_hash", ctypes.c_uint64),
                 ("name", ctypes.c_char*64)]
 
@@ -62,6 +63,8 @@ SYMBOLS = [
     ("gfhip_set_buffer", _I, [_P, _U64, _P, _S, _U32]),
     ("gfhip_kernel_get_info", _I, [_P, ctypes.POINTER(KernelInfo)]),
     ("gfhip_generate_source", _P, [_P, _S, ctypes.POINTER(_U64)]),
+    ("gfhip_generate_piece_source", _I, [_P, _S, _U32, ctypes.POINTER(_P), ctypes.POINTER(_U64)]),
+    ("gfhip_export_piece", _I, [_P, _S, _U32, ctypes.POINTER(_P), ctypes.POINTER(_S)]),
     ("gfhip_free_string", None, [_P]),
     ("gfhip_cli_distribution", None, [_U64, _S, _P, _P, _P]),
     ("gfhip_enable_timing", _I, [_P, _I]),

@@ -257,3 +257,49 @@ def generate_source(gfir):
     source = ctypes.string_at(text).decode()
     lib.gfhip_free_string(text)
     return source, source_hash.value
+
+
+def generate_piece_sources(gfir):
+    """[(HIP source, cache hash)] of the kernels an item runs as: one for most items, one per
+    segment for items the lowering cuts into segments (csrc/segments.hpp)."""
+    lib = _lib.load()
+    if not isinstance(gfir, (bytes, bytearray)):
+        with open(gfir, "rb") as f:
+            gfir = f.read()
+    pieces = []
+    while True:
+        text, source_hash = ctypes.c_void_p(), ctypes.c_uint64()
+        if lib.gfhip_generate_piece_source(gfir, len(gfir), len(pieces), ctypes.byref(text), ctypes.byref(source_hash)):
+            raise GfHipError(lib.gfhip_last_error(None).decode())
+        if not text:
+            return pieces
+        pieces.append((ctypes.string_at(text).decode(), source_hash.value))
+        lib.gfhip_free_string(text)
+
+
+def export_pieces(gfir):
+    """The segments of an item as data (no device): a list of dicts with the piece as GFIR bytes
+    and what its symbols and outputs are (include/gf_hip.h, gfhip_export_piece); [] for an item
+    that runs as one kernel."""
+    import numpy as np
+    lib = _lib.load()
+    if not isinstance(gfir, (bytes, bytearray)):
+        with open(gfir, "rb") as f:
+            gfir = f.read()
+    pieces = []
+    while True:
+        block, size = ctypes.c_void_p(), ctypes.c_size_t()
+        if lib.gfhip_export_piece(gfir, len(gfir), len(pieces), ctypes.byref(block), ctypes.byref(size)):
+            raise GfHipError(lib.gfhip_last_error(None).decode())
+        if not block:
+            return pieces
+        data = ctypes.string_at(block, size.value)
+        lib.gfhip_free_string(block)
+        symbols, outputs, slots, count = np.frombuffer(data, dtype="<i4", count=4)
+        words = np.frombuffer(data, dtype="<i4", count=4 + 2*symbols + 2*outputs)
+        at = 4
+        fields = {}
+        for name, length in (("symbol_state", symbols), ("symbol_slot", symbols), ("output_slot", outputs), ("output_original", outputs)):
+            fields[name] = [int(w) for w in words[at:at + length]]
+            at += length
+        pieces.append(dict(fields, slots=int(slots), pieces=int(count), gfir=data[4*at:]))

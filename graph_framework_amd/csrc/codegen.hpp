@@ -72,11 +72,26 @@ struct lowered {
     uint32_t park_slots = 0;            ///< LDS slots used for parked values
     bool has_converge = false;          ///< the module also holds `<name>_converge`
     bool has_max = false;               ///< the module also holds `<name>_max`
+    uint32_t batch = 0;                 ///< the module also holds `<name>_batch`: up to this many passes per launch, each with its own max
     uint64_t hash = 0;
 };
 
 ///  Entry points of one item's module.
-enum class entry { plain, max, converge };
+enum class entry { plain, max, converge, batch };
+
+///  What a lowered item is within a segmented item whose out-of-window lanes are redone by a separate
+///  launch instead of an IEEE function compiled into every kernel (segments.hpp):
+///    middle  a segment that is not the last: a lane that fails a check raises its per-ray flag;
+///    last    the last segment: a lane that failed a check here or in an earlier segment skips its stores
+///            and appends its ray index to the redo list (one atomicAdd per wavefront that has such lanes);
+///    redo    the WHOLE item with the compiler's division over the rays of the redo list, from the state
+///            the segments left untouched.
+enum class piece_role { none, middle, last, redo };
+
+struct piece_info {
+    piece_role role = piece_role::none;
+    std::vector<bool> output_handed_over;       ///< per output: a hand-over value (no stored-value checks apply to it)
+};
 
 //------------------------------------------------------------------------------
 ///  @brief Writes the kernel text of one lowered item.
@@ -95,6 +110,7 @@ struct kernel_writer {
     const uint32_t park_slots;
     const bool use_shared;                          ///< shared-reciprocal division with the IEEE second body
     const std::vector<bool> &after_division;        ///< node depends on the result of a division
+    const piece_info &piece;                        ///< role within a segmented item with a redo launch
 
     const bool f64 = it.base_is_f64();
     const bool cx = it.is_complex();                ///< values are gf_complex (prelude.hpp)
@@ -102,6 +118,7 @@ struct kernel_writer {
     const bool generic = cx || safe || it.has_random();     ///< operations go through the gf_* names
     const bool track_numerators = opt.division == division_mode::checked && it.base_is_f64();   // fp32 quotients go through fp64: nothing to track
     const bool fixup = division_fixup(it, opt);
+    const bool fast = opt.division == division_mode::fast;      ///< tolerance mode: no residual step, no checks
     const char *real = f64 ? "double" : "float";
     const std::string sfx = f64 ? "" : "f";
     const size_t esize = it.element_size();
@@ -157,7 +174,7 @@ struct kernel_writer {
                 if (f64) {
                     s << "                const real " << quotient << " = gf_div(" << N(arg) << " - " << literal(offset) << ", " << literal(scale) << ", "
                       << literal(1.0/scale) << ");\n";
-                    s << "                vmax = __builtin_elementwise_maximum(vmax, gf_magnitude(" << quotient << "));\n";
+                    if (!fast) s << "                vmax = __builtin_elementwise_maximum(vmax, gf_magnitude(" << quotient << "));\n";
                 } else {
 //  fp32: the reciprocal is the double nearest to 1/scale (prelude.hpp: quotients through fp64)
                     char wide[64];
@@ -247,8 +264,10 @@ struct kernel_writer {
                         if (!reciprocal_done[c.b]) {
                             reciprocal_done[c.b] = true;
                             s << ind << (f64 ? "const real q" : "const double q") << c.b << " = gf_rcp(" << N(c.b) << ");\n";
-                            s << ind << "dmax = __builtin_elementwise_maximum(dmax, gf_magnitude(" << N(c.b) << "));\n";
-                            s << ind << "dmin = __builtin_elementwise_minimum(dmin, gf_magnitude(" << N(c.b) << "));\n";
+                            if (!fast) {
+                                s << ind << "dmax = __builtin_elementwise_maximum(dmax, gf_magnitude(" << N(c.b) << "));\n";
+                                s << ind << "dmin = __builtin_elementwise_minimum(dmin, gf_magnitude(" << N(c.b) << "));\n";
+                            }
                         }
                         if (track_numerators) {
                             s << ind << "nmin = __builtin_elementwise_min(nmin, gf_numerator_key(" << N(c.a) << "));\n";
@@ -280,7 +299,7 @@ struct kernel_writer {
 //  pow tells -0 from +0 when the exponent is an odd integer (pow(-0, -1) = -inf, pow(+0, -1) = +inf): a base
 //  that comes from a shared-reciprocal quotient (whose zero may carry the wrong sign without v_div_fixup) joins
 //  the zero check unless the exponent is a constant that is not an odd integer.
-                    if (shared && f64 && !fixup && after_division[c.a]) {
+                    if (shared && f64 && !fixup && !fast && after_division[c.a]) {
                         const gfir_instruction &e = it.code[c.b];
                         const bool harmless = e.op == GFIR_CONST &&
                                               !(e.imm[0] == std::floor(e.imm[0]) && std::fmod(std::fabs(e.imm[0]), 2.0) == 1.0);
@@ -414,16 +433,29 @@ struct kernel_writer {
         signature(which);
         lds_setup();
         tile_open(which);
-        pass_open(which);
-        pass(which);
+        if (which == entry::batch) {
+//  `<name>_batch`: up to opt.converge_batch passes per launch on state kept in registers, EVERY pass with
+//  its own max (converge loops decide pass by pass, gf_hip.cpp), the state of the beginning of the launch
+//  saved in the undo arrays first (the loop may turn out to have ended inside the batch).
+            for (uint32_t b = 0; b < opt.converge_batch; b++) {
+                batch_pass = static_cast<int> (b);
+                pass_open(which);
+                pass(which);
+            }
+            batch_pass = -1;
+        } else {
+            pass_open(which);
+            pass(which);
+        }
         stores(which);
     }
+    int batch_pass = -1;                            ///< which unrolled pass of `<name>_batch` is being written
 
 //  Kernel name, arguments.
     void signature(const entry which) {
         s << "extern \"C\" __global__ void __launch_bounds__(" << out.block_size;
         if (opt.waves_per_simd) s << ", " << opt.waves_per_simd;
-        s << ")\n" << out.kernel_name << (which == entry::converge ? "_converge" : which == entry::max ? "_max" : "") << "(";
+        s << ")\n" << out.kernel_name << (which == entry::converge ? "_converge" : which == entry::max ? "_max" : which == entry::batch ? "_batch" : "") << "(";
         for (size_t i = 0; i < it.symbols.size(); i++) {
             s << (out.input_written[i] ? "" : "const ") << "real *__restrict__ in" << i << ", ";
         }
@@ -435,8 +467,20 @@ struct kernel_writer {
         }
         if (it.has_random()) s << "gf_mt_state *__restrict__ random_states, ";
         s << "unsigned int *__restrict__ flags, const unsigned long long n, ";
+        if (piece.role == piece_role::middle) s << "unsigned char *__restrict__ flagged, ";
+        if (piece.role == piece_role::last) {
+            s << "unsigned char *__restrict__ flagged, unsigned int *__restrict__ redo_list, unsigned int *__restrict__ redo_count, "
+              << "const unsigned int first, ";
+        }
+        if (piece.role == piece_role::redo) {
+            s << "unsigned char *__restrict__ flagged, const unsigned int *__restrict__ redo_list, const unsigned int *__restrict__ redo_count, ";
+        }
         if (which == entry::converge) {
             s << "const real tolerance,\n        const unsigned int max_iterations, unsigned int *__restrict__ iterations) {\n";
+        } else if (which == entry::batch) {
+            s << "const unsigned int steps,\n        unsigned long long *__restrict__ reduce, const unsigned int *__restrict__ stop";
+            for (size_t k = 0; k < it.setters.size(); k++) s << ", real *__restrict__ undo" << k;
+            s << ") {\n    if (stop && *stop) return;\n";
         } else if (which == entry::max) {
             s << "const unsigned int steps,\n        unsigned long long *__restrict__ reduce, const unsigned int *__restrict__ stop) {\n"
 //  A converge loop enqueues its passes ahead of the host (gf_hip.cpp): once the loop's test has
@@ -480,13 +524,29 @@ struct kernel_writer {
         if (which == entry::max) {
             s << "    real lane_max = -__builtin_huge_val" << sfx << "();\n";
         }
+        if (which == entry::batch) {
+            for (uint32_t b = 0; b < opt.converge_batch; b++) {
+                s << "    real lane_max" << b << " = -__builtin_huge_val" << sfx << "();\n";
+            }
+        }
         if (it.has_random()) {
 //  cuda_context.hpp:509-522, :817: thread t of the (sequentially launched) blocks owns state t and
 //  draws for elements t, t + 1024, ... in that order; the launch has at most 1024 lanes (gf_hip.cpp).
             s << "    gf_mt_state &random_state = random_states[blockIdx.x*blockDim.x + threadIdx.x];\n";
         }
-        s << "    for (unsigned long long i = blockIdx.x*static_cast<unsigned long long> (blockDim.x) + threadIdx.x; i < n;\n"
-          << "         i += gridDim.x*static_cast<unsigned long long> (blockDim.x)) {\n";
+        if (piece.role == piece_role::redo) {
+//  The rays of the redo list (ensemble indices); nothing to do, and nothing read but the count, when it is empty.
+            s << "    const unsigned int redo_total = *redo_count;\n"
+              << "    for (unsigned long long j = blockIdx.x*static_cast<unsigned long long> (blockDim.x) + threadIdx.x; j < redo_total;\n"
+              << "         j += gridDim.x*static_cast<unsigned long long> (blockDim.x)) {\n"
+              << "        const unsigned long long i = redo_list[j];\n"
+              << "        if (i >= n) continue;\n"
+              << "        flagged[i] = 0;\n";
+        } else {
+            s << "    for (unsigned long long i = blockIdx.x*static_cast<unsigned long long> (blockDim.x) + threadIdx.x; i < n;\n"
+              << "         i += gridDim.x*static_cast<unsigned long long> (blockDim.x)) {\n";
+        }
+        if (piece.role == piece_role::last) s << "        bool redo = flagged[i] != 0;\n";
         for (size_t i = 0; i < it.symbols.size(); i++) {
             std::string symbol = it.symbols[i];
             for (auto &ch : symbol) {
@@ -501,6 +561,11 @@ struct kernel_writer {
         for (size_t o = 0; o < it.outputs.size(); o++) {
             s << "        real o" << o << " = " << value_literal(0.0) << ";\n";
         }
+        if (which == entry::batch) {
+            for (size_t k = 0; k < it.setters.size(); k++) {
+                s << "        __builtin_nontemporal_store(v" << it.setters[k].input << ", undo" << k << " + i);\n";
+            }
+        }
     }
 
 //  One pass over the tile: the per-ray converge loop, or `steps` passes of the body.
@@ -511,6 +576,9 @@ struct kernel_writer {
               << "        real last_max = " << (f64 ? "__DBL_MAX__" : "__FLT_MAX__") << ", off_last_max = last_max;\n"
               << "        for (;;) {\n"
               << "            if (active) {\n";
+        } else if (which == entry::batch) {
+            s << "        if (" << batch_pass << "u < steps) {\n";
+            s << "            {\n";
         } else {
             s << "        for (unsigned int step = 0; step < steps; step++) {\n";
             s << "            {\n";
@@ -526,7 +594,12 @@ struct kernel_writer {
 //  The body with its checks and its IEEE second body, the write-back into the lane's state,
 //  the end of the pass loop.
     void pass(const entry which) {
-        if (use_shared) {
+        if (use_shared && fast) {
+//  Tolerance mode (GFHIP_DIVISION=fast): the shared-reciprocal body, nothing to check, nothing to redo.
+            s << "            {\n";
+            body(true);
+            s << "            }\n";
+        } else if (use_shared) {
             s << "            bool bad = false, zero = false;\n";
             s << "            {\n";
             s << "                float dmax = gf_magnitude(" << literal(1.0) << "), dmin = dmax;   // extreme |denominator| of this pass\n";
@@ -543,6 +616,8 @@ struct kernel_writer {
                 if (after_division[it.setters[k].value]) quotient_results.push_back("sv" + std::to_string(k));
             }
             for (size_t o = 0; f64 && o < it.outputs.size(); o++) {
+//  A handed-over value is not a stored value: a non-finite or zero one is seen where it ends up.
+                if (o < piece.output_handed_over.size() && piece.output_handed_over[o]) continue;
                 s << "                vmax = __builtin_elementwise_maximum(vmax, gf_magnitude(so" << o << "));\n";
                 if (after_division[it.outputs[o]]) quotient_results.push_back("so" + std::to_string(o));
             }
@@ -569,6 +644,14 @@ struct kernel_writer {
 //  pass are still in v*).  Status bit 0: a window/finite check failed; bit 1: a stored zero that
 //  came from a quotient.  A bit is set once: lanes that find it set only read it (an atomic per
 //  flagged lane on one address serialises at ~11 ns each).
+            if (piece.role == piece_role::middle || piece.role == piece_role::last) {
+//  No IEEE function in this kernel: the lane is redone by the redo launch (segments.hpp).
+                s << "            if (__builtin_expect(bad || zero, 0)) {\n"
+                  << "                const unsigned int why = bad ? 1u : 2u;\n"
+                  << "                if ((__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & why) == 0u) atomicOr(flags, why);\n"
+                  << (piece.role == piece_role::middle ? "                flagged[i] = 1;\n" : "                redo = true;\n")
+                  << "            }\n";
+            } else {
             s << "            if (__builtin_expect(bad || zero, 0)) {\n"
               << "                const unsigned int why = bad ? 1u : 2u;\n"
               << "                if ((__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & why) == 0u) atomicOr(flags, why);\n"
@@ -583,6 +666,7 @@ struct kernel_writer {
             for (size_t k = 0; k < it.setters.size(); k++) s << "                sv" << k << " = redo.sv" << k << ";\n";
             for (size_t o = 0; o < it.outputs.size(); o++) s << "                so" << o << " = redo.so" << o << ";\n";
             s << "            }\n";
+            }
         } else {
             s << "            {\n";
             body(false);
@@ -609,6 +693,14 @@ struct kernel_writer {
               << "            if (__ballot(active) == 0ull) break;   // the whole wavefront has stalled\n"
               << "        }\n"
               << "        atomicMax(iterations, count);\n";
+        } else if (which == entry::batch) {
+//  The max of this pass's last output, std::max_element's way (see the `_max` epilogue in stores()).
+            const std::string last = "o" + std::to_string(it.outputs.size() - 1);
+            const std::string lane = "lane_max" + std::to_string(batch_pass);
+            s << "            " << lane << " = " << last << " > " << lane << " ? " << last << " : " << lane << ";\n";
+            s << "            if (i == 0ull && " << last << " != " << last << ") " << lane << " = " << last << ";\n";
+            s << "            }\n";
+            s << "        }\n";
         } else {
             s << "            }\n";
             s << "        }\n";
@@ -616,6 +708,22 @@ struct kernel_writer {
     }
 
     void stores(const entry which) {
+        if (piece.role == piece_role::last) {
+//  Lanes to redo leave their state untouched and line up in the redo list: one atomicAdd per
+//  wavefront that has any, the lanes of the wavefront take consecutive places.
+            s << "        {\n"
+              << "            const unsigned long long redo_lanes = __ballot(redo);\n"
+              << "            if (redo_lanes) {\n"
+              << "                const unsigned int lane = threadIdx.x & 63u;\n"
+              << "                const unsigned int leader = static_cast<unsigned int> (__builtin_ctzll(redo_lanes));\n"
+              << "                unsigned int base = 0;\n"
+              << "                if (lane == leader) base = atomicAdd(redo_count, static_cast<unsigned int> (__builtin_popcountll(redo_lanes)));\n"
+              << "                base = __shfl(base, static_cast<int> (leader), 64);\n"
+              << "                if (redo) redo_list[base + static_cast<unsigned int> (__builtin_popcountll(redo_lanes & ((1ull << lane) - 1ull)))] = first + static_cast<unsigned int> (i);\n"
+              << "            }\n"
+              << "        }\n"
+              << "        if (!redo) {\n";
+        }
 //  Stores: setters first, then outputs (cpu_context.hpp:522-580).
         for (size_t i = 0; i < it.symbols.size(); i++) {
             if (!out.input_written[i]) continue;
@@ -632,6 +740,7 @@ struct kernel_writer {
                 s << "        out" << o << "[i] = o" << o << ";\n";
             }
         }
+        if (piece.role == piece_role::last) s << "        }\n";
         if (which == entry::max) {
 //  The max of the last output (create_max_call's argument) as cpu_context takes it — std::max_element,
 //  cpu_context.hpp:306-322: a NaN is never selected, unless it is element 0, which then stays the
@@ -642,34 +751,46 @@ struct kernel_writer {
         }
         s << "    }\n";
         if (which == entry::max) {
+            max_epilogue("lane_max", "reduce", "wave_max");
+        }
+        if (which == entry::batch) {
+            for (uint32_t b = 0; b < opt.converge_batch; b++) {
+                s << "    if (" << b << "u < steps) {\n";
+                max_epilogue("lane_max" + std::to_string(b), "(reduce + " + std::to_string(b) + ")", "wave_max" + std::to_string(b));
+                s << "    }\n";
+            }
+        }
+        s << "}\n";
+    }
+
 //  Epilogue of create_max_call: 64-lane shuffle reduction, one LDS word per wave, ONE
 //  device-scope atomicMax per workgroup on an order-preserving integer image of the value
 //  (max is exact and order independent: the same bits as a serial scan).
-            const char *bits = f64 ? "unsigned long long" : "unsigned int";
-            s << "    for (int offset = 32; offset > 0; offset >>= 1) {\n"
-              << "        const real other = __shfl_down(lane_max, offset, 64);\n"
-              << "        lane_max = other > lane_max ? other : lane_max;\n"
-              << "    }\n"
-              << "    __shared__ real wave_max[" << out.block_size/64 << "];\n"
-              << "    if ((threadIdx.x & 63u) == 0u) wave_max[threadIdx.x >> 6] = lane_max;\n"
-              << "    __syncthreads();\n"
-              << "    if (threadIdx.x == 0u) {\n"
-              << "        real block_max = wave_max[0];\n"
-              << "        for (unsigned int w = 1; w < (blockDim.x >> 6); w++) block_max = wave_max[w] > block_max ? wave_max[w] : block_max;\n"
-              << "        const " << bits << " b = __builtin_bit_cast(" << bits << ", block_max);\n"
-              << "        const " << bits << " top = static_cast<" << bits << "> (1) << " << (f64 ? 63 : 31) << ";\n"
-              << "        atomicMax(reduce, static_cast<unsigned long long> (block_max != block_max ? static_cast<" << bits << "> (~static_cast<" << bits << "> (0))\n"
-              << "                                                             : (b & top) ? static_cast<" << bits << "> (~b) : (b | top)));\n"
-              << "    }\n";
-        }
-        s << "}\n";
+    void max_epilogue(const std::string &lane, const std::string &target, const std::string &scratch) {
+        const char *bits = f64 ? "unsigned long long" : "unsigned int";
+        s << "    for (int offset = 32; offset > 0; offset >>= 1) {\n"
+          << "        const real other = __shfl_down(" << lane << ", offset, 64);\n"
+          << "        " << lane << " = other > " << lane << " ? other : " << lane << ";\n"
+          << "    }\n"
+          << "    __shared__ real " << scratch << "[" << out.block_size/64 << "];\n"
+          << "    if ((threadIdx.x & 63u) == 0u) " << scratch << "[threadIdx.x >> 6] = " << lane << ";\n"
+          << "    __syncthreads();\n"
+          << "    if (threadIdx.x == 0u) {\n"
+          << "        real block_max = " << scratch << "[0];\n"
+          << "        for (unsigned int w = 1; w < (blockDim.x >> 6); w++) block_max = " << scratch << "[w] > block_max ? " << scratch << "[w] : block_max;\n"
+          << "        const " << bits << " b = __builtin_bit_cast(" << bits << ", block_max);\n"
+          << "        const " << bits << " top = static_cast<" << bits << "> (1) << " << (f64 ? 63 : 31) << ";\n"
+          << "        atomicMax(" << target << ", static_cast<unsigned long long> (block_max != block_max ? static_cast<" << bits << "> (~static_cast<" << bits << "> (0))\n"
+          << "                                                             : (b & top) ? static_cast<" << bits << "> (~b) : (b | top)));\n"
+          << "    }\n";
     }
 };
 
 //------------------------------------------------------------------------------
 ///  @brief Lower one item.
 //------------------------------------------------------------------------------
-inline lowered lower(const item &original, const codegen_options &opt = codegen_options::from_environment()) {
+inline lowered lower(const item &original, const codegen_options &opt = codegen_options::from_environment(),
+                     const piece_info &piece = piece_info()) {
     item scheduled;
     if (opt.schedule_for_pressure) {
         scheduled = schedule_for_pressure(original);
@@ -725,7 +846,7 @@ inline lowered lower(const item &original, const codegen_options &opt = codegen_
     emit_prelude(s, it, opt, out.packs.size());
 //  Items without a division node need neither the checks nor the second body (their gather
 //  indices then divide by the literal scale).
-    const bool use_shared = opt.division != division_mode::ieee && divides && !generic;
+    const bool use_shared = opt.division != division_mode::ieee && divides && !generic && piece.role != piece_role::redo;
 //  Entry points: `<name>` runs `steps` passes.  Small items with an output also get `<name>_max`
 //  (the same, plus the max of the last output reduced inside the launch: create_max_call) and,
 //  with a setter, `<name>_converge`, which runs the stall loop of workflow.hpp:179-205 PER RAY
@@ -733,18 +854,22 @@ inline lowered lower(const item &original, const codegen_options &opt = codegen_
 //  the ballot of still-active lanes is empty.  That is the reference's converge loop applied to
 //  each ray as its own shard; it equals the reference's global-max loop when the rays are
 //  identical (the benchmark) and is offered as gfhip_converge_per_ray.
-    const bool small = it.code.size() <= 1500;
+    const bool small = it.code.size() <= 1500 && piece.role == piece_role::none;
     out.has_max = !it.outputs.empty() && small && !it.is_complex() && !it.has_random();
     out.has_converge = out.has_max && !it.setters.empty();
     codegen_options resolved = opt;
     if (resolved.nontemporal < 0) resolved.nontemporal = it.code.size() >= 100 ? 1 : 0;
     kernel_writer writer{s, it, resolved, out, parent, factor, table_pack, table_column, plan, lds_used, park_offset, park_slots,
-                         use_shared, after_division};
+                         use_shared, after_division, piece};
     if (park_slots) s << "typedef __attribute__((address_space(3))) real park_t;\n";
-    if (use_shared) writer.ieee_function();
+    if (use_shared && piece.role == piece_role::none && opt.division != division_mode::fast) writer.ieee_function();
     writer.kernel(entry::plain);
     if (out.has_max) writer.kernel(entry::max);
     if (out.has_converge) writer.kernel(entry::converge);
+    if (out.has_converge && resolved.converge_batch > 1) {
+        out.batch = resolved.converge_batch;
+        writer.kernel(entry::batch);
+    }
 
     out.source = s.str();
     out.hash = fnv1a(out.source + "|" + compile_flags());

@@ -16,6 +16,9 @@ struct converge_state {
     unsigned long long limit;       ///< max_iterations
     unsigned int done;              ///< the loop's condition came out false: later passes return at once
     unsigned int passes;            ///< passes that really ran
+    unsigned int extra;             ///< batched passes (`<name>_batch`): passes of the last batch that ran BEYOND the loop's last
+                                    ///< one — the state is then restored from the undo arrays and the batch redone without them
+    unsigned int batch_passes;      ///< passes of the last batch that belong to the loop
 };
 
 }  // namespace gfhip

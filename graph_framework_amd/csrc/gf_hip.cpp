@@ -29,6 +29,7 @@
 
 #include "../../include/gf_hip.h"
 #include "codegen.hpp"
+#include "segments.hpp"
 
 #include "converge_state.hpp"
 
@@ -36,6 +37,7 @@ namespace gfhip {
 void launch_max_reduce(const void *in, const size_t n, const bool f64,
                        unsigned long long *result, const unsigned int num_cus, hipStream_t stream);
 void launch_converge_decide(const bool f64, unsigned long long *reduced, void *state, hipStream_t stream);
+void launch_converge_decide_batch(const bool f64, unsigned long long *reduced, void *state, const unsigned int count, hipStream_t stream);
 void launch_max_modulus(const void *in, const size_t n, const bool f64, void *result, hipStream_t stream);
 }
 
@@ -112,15 +114,36 @@ struct gfhip_context {
     }
 };
 
+//  One compiled kernel of a work item: the item itself, or one segment of it (segments.hpp).
+struct built_piece {
+    gfhip::segment plan;                           // the piece as an item, and what its symbols and outputs are
+    gfhip::lowered low;
+    hipModule_t module = nullptr;
+    hipFunction_t function = nullptr;
+    std::vector<void *> pack_device;
+    unsigned int grid = 1;
+    int vgprs = 0, lds_static = 0, scratch = 0;
+    bool from_cache = false;
+};
+
 struct gfhip_kernel {
     gfhip_context *ctx = nullptr;
     gfhip::item item;
     gfhip::lowered low;
+    std::vector<built_piece> pieces;               // non-empty: the item runs as this sequence of segment kernels
+    std::vector<void *> handover;                  // one device array of `chunk` elements per hand-over slot
+    size_t chunk = 0;                              // rays per walk of the segment sequence
+    bool has_redo = false;                         // lanes outside the division window are redone by `redo`, a launch of its own
+    built_piece redo;                              // the whole item with the compiler's division, over the redo list
+    unsigned char *flagged = nullptr;              // per ray: a segment before the last found it outside the window
+    unsigned int *redo_list = nullptr, *redo_count = nullptr;
     size_t num_rays = 0;
     hipModule_t module = nullptr;
     hipFunction_t function = nullptr;
     hipFunction_t converge_function = nullptr;
     hipFunction_t max_function = nullptr;
+    hipFunction_t batch_function = nullptr;         // `<name>_batch`: several passes per launch, one max per pass
+    std::vector<void *> undo;                      // per setter: the target's values at the beginning of the last batch
     bool built = false;
     bool from_cache = false;
     std::vector<void *> pack_device;
@@ -200,7 +223,8 @@ extern "C" gfhip_context *gfhip_create_context(int index, void *stream) {
     }
     if (hipMalloc(reinterpret_cast<void **> (&ctx->device_flags), sizeof(unsigned int)) != hipSuccess ||
         hipMemset(ctx->device_flags, 0, sizeof(unsigned int)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void **> (&ctx->device_scalar), sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **> (&ctx->device_scalar), 8*sizeof(unsigned long long)) != hipSuccess ||     // one per pass of a batch
+        hipMemset(ctx->device_scalar, 0, 8*sizeof(unsigned long long)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **> (&ctx->host_scalar), sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **> (&ctx->device_converge), sizeof(gfhip::converge_state)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **> (&ctx->host_converge), sizeof(gfhip::converge_state), hipHostMallocDefault) != hipSuccess) {
@@ -215,6 +239,25 @@ static void release_kernel(gfhip_kernel *k) {
     for (void *p : k->pack_device) {
         if (p) (void)hipFree(p);
     }
+    for (auto &piece : k->pieces) {
+        for (void *p : piece.pack_device) {
+            if (p) (void)hipFree(p);
+        }
+        if (piece.module) (void)hipModuleUnload(piece.module);
+    }
+    for (void *p : k->handover) {
+        if (p) (void)hipFree(p);
+    }
+    for (void *p : k->redo.pack_device) {
+        if (p) (void)hipFree(p);
+    }
+    for (void *p : k->undo) {
+        if (p) (void)hipFree(p);
+    }
+    if (k->redo.module) (void)hipModuleUnload(k->redo.module);
+    if (k->flagged) (void)hipFree(k->flagged);
+    if (k->redo_list) (void)hipFree(k->redo_list);
+    if (k->redo_count) (void)hipFree(k->redo_count);
     for (auto &e : k->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto &e : k->free_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (k->module) (void)hipModuleUnload(k->module);
@@ -241,6 +284,66 @@ extern "C" void gfhip_destroy_context(gfhip_context *ctx) {
     delete ctx;
 }
 
+//  How an item is compiled: as one kernel (`pieces` stays empty, `whole` is its lowering), or — items of
+//  more than options.segment_nodes records, or every large item when GFHIP_SEGMENTS asks for it — as a
+//  sequence of segment kernels (segments.hpp).  Returns the number of hand-over slots.
+static uint32_t plan_item(const gfhip::item &it, gfhip::lowered &whole, std::vector<built_piece> &pieces,
+                          built_piece *redo = nullptr, bool *has_redo = nullptr) {
+    const gfhip::codegen_options opt = gfhip::codegen_options::from_environment();
+    size_t count = 1;
+    bool automatic = false;
+    if (gfhip::can_split(it)) {
+        if (opt.segments > 1 && it.code.size() >= 2000) {
+            count = opt.segments;
+        } else if (opt.segment_nodes && it.code.size() > opt.segment_nodes) {
+            count = (it.code.size() + opt.segment_nodes - 1)/opt.segment_nodes;
+            automatic = true;
+        }
+    }
+    if (count < 2) {
+        whole = gfhip::lower(it, opt);
+        return 0;
+    }
+//  Cut in the pressure-aware emission order where that is affordable (schedule.hpp), else in the order given.
+    const gfhip::item ordered = opt.schedule_for_pressure ? gfhip::schedule_for_pressure(it) : it;
+    gfhip::segmentation plan = gfhip::split_item(ordered, gfhip::choose_cuts(ordered, count));
+    gfhip::codegen_options piece_options = opt;
+//  Very large items are off the hot path: the compiler's division, no checks, no second body.
+    if (automatic) piece_options.division = gfhip::division_mode::ieee;
+//  The experiment on hot items keeps the shared-reciprocal division and compiles NO IEEE function into the
+//  segments (so that they fit two waves per SIMD): lanes outside the window are redone by one more launch.
+    const bool with_redo = !automatic && piece_options.division != gfhip::division_mode::ieee;
+    for (size_t p = 0; p < plan.segments.size(); p++) {
+        built_piece piece;
+        gfhip::piece_info role;
+        if (with_redo) {
+            role.role = p + 1 == plan.segments.size() ? gfhip::piece_role::last : gfhip::piece_role::middle;
+            for (auto slot : plan.segments[p].output_slot) role.output_handed_over.push_back(slot >= 0);
+        }
+        piece.low = gfhip::lower(plan.segments[p].piece, piece_options, role);
+        piece.plan = std::move(plan.segments[p]);
+        pieces.push_back(std::move(piece));
+    }
+    if (has_redo) *has_redo = with_redo;
+    if (with_redo && redo) {
+        gfhip::piece_info role;
+        role.role = gfhip::piece_role::redo;
+        gfhip::codegen_options plain = opt;
+        plain.division = gfhip::division_mode::ieee;
+        plain.waves_per_simd = 0;
+        redo->plan.piece = it;
+        redo->plan.piece.name = it.name + "_redo";
+        redo->low = gfhip::lower(redo->plan.piece, plain, role);
+    }
+    whole = gfhip::lowered();
+    whole.kernel_name = "gfhip_" + it.name;
+    whole.block_size = pieces[0].low.block_size;
+    whole.input_written.assign(it.symbols.size(), false);
+    for (auto &s : it.setters) whole.input_written[s.input] = true;
+    for (auto &piece : pieces) whole.hash = whole.hash*1099511628211ull ^ piece.low.hash;
+    return plan.slots;
+}
+
 extern "C" gfhip_kernel *gfhip_add_kernel(gfhip_context *ctx, const void *gfir, size_t bytes, size_t num_rays) {
     if (!ctx) return nullptr;
     std::unique_ptr<gfhip_kernel> k(new gfhip_kernel);
@@ -249,9 +352,76 @@ extern "C" gfhip_kernel *gfhip_add_kernel(gfhip_context *ctx, const void *gfir, 
     if (!k->item.parse(gfir, bytes, ctx->error)) {
         return nullptr;
     }
-    k->low = gfhip::lower(k->item);
+    const uint32_t slots = plan_item(k->item, k->low, k->pieces, &k->redo, &k->has_redo);
+    if (!k->pieces.empty()) {
+//  Rays per walk of the segment sequence: the hand-over buffers of one chunk stay in the Infinity Cache.
+        const gfhip::codegen_options opt = gfhip::codegen_options::from_environment();
+        size_t chunk = opt.handover_bytes/(static_cast<size_t> (slots ? slots : 1)*k->item.element_size());
+        chunk = chunk/1024*1024;
+        if (chunk < 16384) chunk = 16384;
+        k->chunk = num_rays < chunk ? num_rays : chunk;
+        k->handover.assign(slots, nullptr);
+    }
     ctx->kernels.push_back(std::move(k));
     return ctx->kernels.back().get();
+}
+
+extern "C" int gfhip_export_piece(const void *gfir, size_t bytes, uint32_t index, void **piece, size_t *piece_bytes) {
+    gfhip::item it;
+    std::string error;
+    if (!piece || !piece_bytes) return 1;
+    *piece = nullptr;
+    *piece_bytes = 0;
+    if (!it.parse(gfir, bytes, error)) {
+        creation_error = error;
+        return 1;
+    }
+    gfhip::lowered whole;
+    std::vector<built_piece> pieces;
+    const uint32_t slots = plan_item(it, whole, pieces);
+    if (index >= pieces.size()) return 0;
+    const gfhip::segment &plan = pieces[index].plan;
+    std::vector<int32_t> head = {static_cast<int32_t> (plan.piece.symbols.size()), static_cast<int32_t> (plan.piece.outputs.size()),
+                                 static_cast<int32_t> (slots), static_cast<int32_t> (pieces.size())};
+    head.insert(head.end(), plan.symbol_state.begin(), plan.symbol_state.end());
+    head.insert(head.end(), plan.symbol_slot.begin(), plan.symbol_slot.end());
+    head.insert(head.end(), plan.output_slot.begin(), plan.output_slot.end());
+    head.insert(head.end(), plan.output_original.begin(), plan.output_original.end());
+    const std::vector<uint8_t> body = plan.piece.serialize();
+    *piece_bytes = head.size()*4 + body.size();
+    *piece = std::malloc(*piece_bytes);
+    std::memcpy(*piece, head.data(), head.size()*4);
+    std::memcpy(static_cast<char *> (*piece) + head.size()*4, body.data(), body.size());
+    return 0;
+}
+
+extern "C" int gfhip_generate_piece_source(const void *gfir, size_t bytes, uint32_t index, char **source, uint64_t *source_hash) {
+    gfhip::item it;
+    std::string error;
+    if (!source) return 1;
+    *source = nullptr;
+    if (!it.parse(gfir, bytes, error)) {
+        creation_error = error;
+        return 1;
+    }
+    gfhip::lowered whole;
+    std::vector<built_piece> pieces;
+    built_piece redo;
+    bool has_redo = false;
+    (void)plan_item(it, whole, pieces, &redo, &has_redo);
+    const gfhip::lowered *low = nullptr;
+    if (pieces.empty()) {
+        if (index == 0) low = &whole;
+    } else if (index < pieces.size()) {
+        low = &pieces[index].low;
+    } else if (has_redo && index == pieces.size()) {
+        low = &redo.low;
+    }
+    if (!low) return 0;                                 // past the last piece: *source stays NULL
+    if (source_hash) *source_hash = low->hash;
+    *source = static_cast<char *> (std::malloc(low->source.size() + 1));
+    std::memcpy(*source, low->source.c_str(), low->source.size() + 1);
+    return 0;
 }
 
 extern "C" char *gfhip_generate_source(const void *gfir, size_t bytes, uint64_t *source_hash) {
@@ -261,7 +431,12 @@ extern "C" char *gfhip_generate_source(const void *gfir, size_t bytes, uint64_t 
         creation_error = error;
         return nullptr;
     }
-    const gfhip::lowered low = gfhip::lower(it);
+    gfhip::lowered low;
+    std::vector<built_piece> pieces;
+    (void)plan_item(it, low, pieces);
+//  A segmented item: the texts of its pieces one after the other (each is a translation unit of its
+//  own: gfhip_generate_piece_source hands them out one by one).
+    for (auto &piece : pieces) low.source += piece.low.source;
     if (source_hash) *source_hash = low.hash;
     char *text = static_cast<char *> (std::malloc(low.source.size() + 1));
     std::memcpy(text, low.source.c_str(), low.source.size() + 1);
@@ -272,57 +447,73 @@ extern "C" void gfhip_free_string(char *text) {
     std::free(text);
 }
 
-//  Build one kernel: cached code object (by source hash) or hipRTC.  Module, functions and
-//  packs are built into locals and committed to the kernel only when every step has succeeded,
-//  so a failed build leaves nothing half-initialised behind (a later gfhip_compile retries).
-static int build_kernel(gfhip_context *ctx, gfhip_kernel *k) {
-    const std::string file = hash_name(k->low.hash) + ".hsaco";
+//  The code object of one lowered kernel text: from the kernel cache (by source hash) or hipRTC.
+static int load_code_object(gfhip_context *ctx, const std::string &name, const gfhip::lowered &low,
+                            std::vector<char> &code, bool &from_cache) {
+    const std::string file = hash_name(low.hash) + ".hsaco";
     std::vector<std::string> directories;
     if (const char *env = std::getenv("GFHIP_CACHE_DIR")) directories.push_back(env);
     directories.push_back(library_directory() + "/kernel_cache");
 
-    std::vector<char> code;
-    bool from_cache = false;
+    from_cache = false;
     for (auto &d : directories) {
         if (read_file(d + "/" + file, code)) {
             from_cache = true;
-            break;
+            return 0;
         }
     }
-
-    if (!from_cache) {
-        if (std::getenv("GFHIP_REQUIRE_CACHE")) {
-            return ctx->fail("kernel " + k->item.name + " (" + file + ") not in the kernel cache and GFHIP_REQUIRE_CACHE is set");
-        }
-        hiprtcProgram program;
-        if (hiprtcCreateProgram(&program, k->low.source.c_str(), (k->item.name + ".hip").c_str(), 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
-            return ctx->fail("hiprtcCreateProgram failed");
-        }
-        const char *options[] = {"-O3", "-ffp-contract=off", "--offload-arch=gfx950"};
-        const hiprtcResult result = hiprtcCompileProgram(program, 3, options);
-        if (result != HIPRTC_SUCCESS) {
-            size_t log_size = 0;
-            hiprtcGetProgramLogSize(program, &log_size);
-            std::string log(log_size, '\0');
-            if (log_size) hiprtcGetProgramLog(program, &log[0]);
-            hiprtcDestroyProgram(&program);
-            return ctx->fail("hipRTC failed for " + k->item.name + ": " + log);
-        }
-        size_t size = 0;
-        hiprtcGetCodeSize(program, &size);
-        code.resize(size);
-        hiprtcGetCode(program, code.data());
+    if (std::getenv("GFHIP_REQUIRE_CACHE")) {
+        return ctx->fail("kernel " + name + " (" + file + ") not in the kernel cache and GFHIP_REQUIRE_CACHE is set");
+    }
+    hiprtcProgram program;
+    if (hiprtcCreateProgram(&program, low.source.c_str(), (name + ".hip").c_str(), 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
+        return ctx->fail("hiprtcCreateProgram failed");
+    }
+    const char *options[] = {"-O3", "-ffp-contract=off", "--offload-arch=gfx950"};
+    const hiprtcResult result = hiprtcCompileProgram(program, 3, options);
+    if (result != HIPRTC_SUCCESS) {
+        size_t log_size = 0;
+        hiprtcGetProgramLogSize(program, &log_size);
+        std::string log(log_size, '\0');
+        if (log_size) hiprtcGetProgramLog(program, &log[0]);
         hiprtcDestroyProgram(&program);
-        if (const char *env = std::getenv("GFHIP_CACHE_DIR")) {
-            ::mkdir(env, 0755);
-            std::ofstream f(std::string(env) + "/" + file, std::ios::binary);
-            f.write(code.data(), static_cast<std::streamsize> (code.size()));
-        }
+        return ctx->fail("hipRTC failed for " + name + ": " + log);
     }
+    size_t size = 0;
+    hiprtcGetCodeSize(program, &size);
+    code.resize(size);
+    hiprtcGetCode(program, code.data());
+    hiprtcDestroyProgram(&program);
+    if (const char *env = std::getenv("GFHIP_CACHE_DIR")) {
+        ::mkdir(env, 0755);
+        std::ofstream f(std::string(env) + "/" + file, std::ios::binary);
+        f.write(code.data(), static_cast<std::streamsize> (code.size()));
+    }
+    return 0;
+}
+
+//  What build_module produces for one lowered item.
+struct built_module {
+    hipModule_t module = nullptr;
+    hipFunction_t function = nullptr, max_function = nullptr, converge_function = nullptr, batch_function = nullptr;
+    std::vector<void *> packs;
+    int vgprs = 0, lds_static = 0, scratch = 0;
+    bool from_cache = false;
+    unsigned int grid = 1;
+};
+
+//  Build one kernel of `rays` lanes of work per launch.  Module, functions and packs are built into
+//  `out` and handed to the caller only when every step has succeeded, so a failed build leaves
+//  nothing half-initialised behind (a later gfhip_compile retries).
+static int build_module(gfhip_context *ctx, const gfhip::item &item, const gfhip::lowered &low, const size_t rays,
+                        built_module &out) {
+    std::vector<char> code;
+    bool from_cache = false;
+    if (load_code_object(ctx, item.name, low, code, from_cache)) return 1;
 
     hipModule_t module = nullptr;
-    hipFunction_t function = nullptr, max_function = nullptr, converge_function = nullptr;
-    std::vector<void *> packs(k->low.packs.size(), nullptr);
+    hipFunction_t function = nullptr, max_function = nullptr, converge_function = nullptr, batch_function = nullptr;
+    std::vector<void *> packs(low.packs.size(), nullptr);
     auto abandon = [&] (const int status) {
         for (void *p : packs) {
             if (p) (void)hipFree(p);
@@ -331,34 +522,37 @@ static int build_kernel(gfhip_context *ctx, gfhip_kernel *k) {
         return status;
     };
     if (ctx->check(hipModuleLoadData(&module, code.data()), "hipModuleLoadData")) return abandon(1);
-    if (ctx->check(hipModuleGetFunction(&function, module, k->low.kernel_name.c_str()), "hipModuleGetFunction")) return abandon(1);
-    if (k->low.has_max &&
-        ctx->check(hipModuleGetFunction(&max_function, module, (k->low.kernel_name + "_max").c_str()),
+    if (ctx->check(hipModuleGetFunction(&function, module, low.kernel_name.c_str()), "hipModuleGetFunction")) return abandon(1);
+    if (low.has_max &&
+        ctx->check(hipModuleGetFunction(&max_function, module, (low.kernel_name + "_max").c_str()),
                    "hipModuleGetFunction(max)")) return abandon(1);
-    if (k->low.has_converge &&
-        ctx->check(hipModuleGetFunction(&converge_function, module, (k->low.kernel_name + "_converge").c_str()),
+    if (low.has_converge &&
+        ctx->check(hipModuleGetFunction(&converge_function, module, (low.kernel_name + "_converge").c_str()),
                    "hipModuleGetFunction(converge)")) return abandon(1);
+    if (low.batch > 1 &&
+        ctx->check(hipModuleGetFunction(&batch_function, module, (low.kernel_name + "_batch").c_str()),
+                   "hipModuleGetFunction(batch)")) return abandon(1);
     int vgprs = 0, lds_static = 0, scratch = 0;
     (void)hipFuncGetAttribute(&vgprs, HIP_FUNC_ATTRIBUTE_NUM_REGS, function);
     (void)hipFuncGetAttribute(&lds_static, HIP_FUNC_ATTRIBUTE_SHARED_SIZE_BYTES, function);
     (void)hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, function);
-    if (k->low.lds_bytes > 48*1024) {
-        for (hipFunction_t f : {function, max_function, converge_function}) {
+    if (low.lds_bytes > 48*1024) {
+        for (hipFunction_t f : {function, max_function, converge_function, batch_function}) {
             if (f) (void)hipFuncSetAttribute(reinterpret_cast<const void *> (f), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             static_cast<int> (k->low.lds_bytes));
+                                             static_cast<int> (low.lds_bytes));
         }
     }
 
 //  Pack and upload the tables: [cell][column], padded to the pack stride.
-    const size_t esize = k->item.element_size();
-    const size_t parts = k->item.is_complex() ? 2 : 1;
-    const bool wide = k->item.base_is_f64();
-    for (size_t p = 0; p < k->low.packs.size(); p++) {
-        const gfhip::pack &pk = k->low.packs[p];
+    const size_t esize = item.element_size();
+    const size_t parts = item.is_complex() ? 2 : 1;
+    const bool wide = item.base_is_f64();
+    for (size_t p = 0; p < low.packs.size(); p++) {
+        const gfhip::pack &pk = low.packs[p];
         const size_t cells = pk.cells();
         std::vector<unsigned char> host(pk.elements()*esize, 0);
         for (size_t column = 0; column < pk.tables.size(); column++) {
-            const gfhip::table &t = k->item.tables[pk.tables[column]];
+            const gfhip::table &t = item.tables[pk.tables[column]];
             for (size_t cell = 0; cell < cells; cell++) {
                 for (size_t part = 0; part < parts; part++) {
                     const size_t at = (cell*pk.stride + column)*parts + part;
@@ -376,8 +570,8 @@ static int build_kernel(gfhip_context *ctx, gfhip_kernel *k) {
 
 //  Launch geometry: one lane per ray; the kernel grid-strides, so cap the grid
 //  at a few waves of workgroups per CU.
-    const size_t block = k->low.block_size;
-    size_t want = (k->num_rays + block - 1)/block;
+    const size_t block = low.block_size;
+    size_t want = (rays + block - 1)/block;
     if (want < 1) want = 1;
 //  Persistent-style grid: a few workgroups per resident slot, the kernel grid-strides.
 //  Measured (1e7-particle fp64 push): exact grid 0.276 ms, 64 per CU 0.245, 16 per CU 0.235.
@@ -386,7 +580,7 @@ static int build_kernel(gfhip_context *ctx, gfhip_kernel *k) {
 //  rays (the coefficient packs are staged into LDS once per workgroup instead of 15 times).
     int resident = 0;
     if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&resident, function, static_cast<int> (block),
-                                                           k->low.lds_bytes) != hipSuccess || resident < 1) {
+                                                           low.lds_bytes) != hipSuccess || resident < 1) {
         resident = 1;
     }
     size_t cap = static_cast<size_t> (ctx->num_cus)*static_cast<size_t> (resident)*(resident == 1 ? 1 : 4);
@@ -394,20 +588,106 @@ static int build_kernel(gfhip_context *ctx, gfhip_kernel *k) {
         cap = static_cast<size_t> (ctx->num_cus)*static_cast<size_t> (std::atoi(env) > 0 ? std::atoi(env) : 1);
     }
 
-    k->module = module;
-    k->function = function;
-    k->max_function = max_function;
-    k->converge_function = converge_function;
-    k->pack_device = packs;
-    k->vgprs = vgprs;
-    k->lds_static = lds_static;
-    k->scratch = scratch;
-    k->from_cache = from_cache;
-    k->grid = static_cast<unsigned int> (want < cap ? want : cap);
+    out.module = module;
+    out.function = function;
+    out.max_function = max_function;
+    out.converge_function = converge_function;
+    out.batch_function = batch_function;
+    out.packs = packs;
+    out.vgprs = vgprs;
+    out.lds_static = lds_static;
+    out.scratch = scratch;
+    out.from_cache = from_cache;
+    out.grid = static_cast<unsigned int> (want < cap ? want : cap);
 //  A kernel that draws random numbers: lane t owns MT19937 state t of 1024 and serves elements
 //  t, t + 1024, ... in order (cuda_context.hpp:509-522 launches one 1024-thread block per 1024
 //  elements, one after the other).
-    if (k->item.has_random() && k->grid*block > 1024) k->grid = static_cast<unsigned int> (1024/block);
+    if (item.has_random() && out.grid*block > 1024) out.grid = static_cast<unsigned int> (1024/block);
+    return 0;
+}
+
+static int build_kernel(gfhip_context *ctx, gfhip_kernel *k) {
+    if (!k->pieces.empty()) {
+//  A segmented item: every piece is a kernel of its own over one chunk of rays; one device array
+//  per hand-over slot.  Everything is committed only when every piece has been built.
+        std::vector<built_module> modules(k->pieces.size());
+        std::vector<void *> handover(k->handover.size(), nullptr);
+        auto abandon = [&] (const int status) {
+            for (auto &m : modules) {
+                for (void *p : m.packs) {
+                    if (p) (void)hipFree(p);
+                }
+                if (m.module) (void)hipModuleUnload(m.module);
+            }
+            for (void *p : handover) {
+                if (p) (void)hipFree(p);
+            }
+            return status;
+        };
+        for (size_t p = 0; p < k->pieces.size(); p++) {
+            if (build_module(ctx, k->pieces[p].plan.piece, k->pieces[p].low, k->chunk, modules[p])) return abandon(1);
+        }
+        const size_t bytes = k->chunk*k->item.element_size();
+        for (auto &slot : handover) {
+            if (ctx->check(hipMalloc(&slot, bytes ? bytes : 8), "hipMalloc(hand-over)")) return abandon(1);
+        }
+        if (k->has_redo) {
+            built_module redo;
+            if (build_module(ctx, k->redo.plan.piece, k->redo.low, 64*256, redo)) return abandon(1);
+            const size_t rays = k->num_rays ? k->num_rays : 1;
+            if (ctx->check(hipMalloc(reinterpret_cast<void **> (&k->flagged), rays), "hipMalloc(flagged)") ||
+                ctx->check(hipMemset(k->flagged, 0, rays), "hipMemset(flagged)") ||
+                ctx->check(hipMalloc(reinterpret_cast<void **> (&k->redo_list), rays*sizeof(unsigned int)), "hipMalloc(redo list)") ||
+                ctx->check(hipMalloc(reinterpret_cast<void **> (&k->redo_count), sizeof(unsigned int)), "hipMalloc(redo count)") ||
+                ctx->check(hipMemset(k->redo_count, 0, sizeof(unsigned int)), "hipMemset(redo count)")) {
+                for (void *p : redo.packs) {
+                    if (p) (void)hipFree(p);
+                }
+                (void)hipModuleUnload(redo.module);
+                return abandon(1);
+            }
+            k->redo.module = redo.module;
+            k->redo.function = redo.function;
+            k->redo.pack_device = redo.packs;
+            k->redo.grid = redo.grid;
+            k->redo.vgprs = redo.vgprs;
+            k->redo.scratch = redo.scratch;
+            k->redo.from_cache = redo.from_cache;
+        }
+        for (size_t p = 0; p < k->pieces.size(); p++) {
+            built_piece &piece = k->pieces[p];
+            piece.module = modules[p].module;
+            piece.function = modules[p].function;
+            piece.pack_device = modules[p].packs;
+            piece.grid = modules[p].grid;
+            piece.vgprs = modules[p].vgprs;
+            piece.lds_static = modules[p].lds_static;
+            piece.scratch = modules[p].scratch;
+            piece.from_cache = modules[p].from_cache;
+            k->vgprs = std::max(k->vgprs, piece.vgprs);
+            k->scratch = std::max(k->scratch, piece.scratch);
+            k->lds_static = std::max(k->lds_static, piece.lds_static);
+        }
+        k->handover = handover;
+        k->from_cache = true;
+        for (auto &piece : k->pieces) k->from_cache = k->from_cache && piece.from_cache;
+        k->grid = k->pieces[0].grid;
+        k->built = true;
+        return 0;
+    }
+    built_module built;
+    if (build_module(ctx, k->item, k->low, k->num_rays, built)) return 1;
+    k->module = built.module;
+    k->function = built.function;
+    k->max_function = built.max_function;
+    k->converge_function = built.converge_function;
+    k->batch_function = built.batch_function;
+    k->pack_device = built.packs;
+    k->vgprs = built.vgprs;
+    k->lds_static = built.lds_static;
+    k->scratch = built.scratch;
+    k->from_cache = built.from_cache;
+    k->grid = built.grid;
     k->built = true;
     return 0;
 }
@@ -500,6 +780,81 @@ extern "C" int gfhip_create_kernel_call(gfhip_kernel *k, const uint64_t *input_k
 
 //  Launch `<name>` (reduce == nullptr) or `<name>_max` (the max of the last output is folded into
 //  *reduce; a non-null `stop` word that reads non-zero makes the launch return at once).
+//  A segmented item (segments.hpp): `steps` passes, each a walk over the ensemble in chunks, each chunk
+//  through the sequence of segment kernels.  A piece's symbols are state arrays (offset to the chunk) or
+//  hand-over slots; its outputs are slots or, in the last piece, the item's outputs.  Only the last
+//  piece stores state, so a chunk's pieces all read the state of the beginning of the pass.
+static int launch_pieces(gfhip_kernel *k, const uint32_t steps) {
+    gfhip_context *ctx = k->ctx;
+    const size_t esize = k->item.element_size();
+    for (uint32_t step = 0; step < steps; step++) {
+        for (size_t first = 0; first < k->num_rays; first += k->chunk) {
+            unsigned long long n = std::min(k->chunk, k->num_rays - first);
+            for (auto &piece : k->pieces) {
+                std::vector<void *> pointers;
+                for (size_t i = 0; i < piece.plan.piece.symbols.size(); i++) {
+                    if (piece.plan.symbol_state[i] >= 0) {
+                        pointers.push_back(static_cast<char *> (ctx->buffers[k->input_keys[piece.plan.symbol_state[i]]].pointer) + first*esize);
+                    } else {
+                        pointers.push_back(k->handover[piece.plan.symbol_slot[i]]);
+                    }
+                }
+                for (size_t o = 0; o < piece.plan.piece.outputs.size(); o++) {
+                    if (piece.plan.output_slot[o] >= 0) {
+                        pointers.push_back(k->handover[piece.plan.output_slot[o]]);
+                    } else {
+                        pointers.push_back(static_cast<char *> (ctx->buffers[k->output_keys[piece.plan.output_original[o]]].pointer) + first*esize);
+                    }
+                }
+                for (void *p : piece.pack_device) pointers.push_back(p);
+                pointers.push_back(ctx->device_flags);
+                unsigned int one = 1;
+                unsigned int first_ray = static_cast<unsigned int> (first);
+                unsigned char *flagged = k->flagged ? k->flagged + first : nullptr;
+                std::vector<void *> params;
+                for (auto &p : pointers) params.push_back(&p);
+                params.push_back(&n);
+                if (k->has_redo) {
+                    params.push_back(&flagged);
+                    if (&piece == &k->pieces.back()) {
+                        params.push_back(&k->redo_list);
+                        params.push_back(&k->redo_count);
+                        params.push_back(&first_ray);
+                    }
+                }
+                params.push_back(&one);
+                const size_t want = (n + piece.low.block_size - 1)/piece.low.block_size;
+                const unsigned int grid = static_cast<unsigned int> (want < piece.grid ? want : piece.grid);
+                GFHIP_TRY(ctx, hipModuleLaunchKernel(piece.function, grid, 1, 1, piece.low.block_size, 1, 1,
+                                                     static_cast<unsigned int> (piece.low.lds_bytes), ctx->stream,
+                                                     params.data(), nullptr), "hipModuleLaunchKernel(segment)");
+            }
+        }
+        if (k->has_redo) {
+//  The lanes the segments left alone: the whole item with the compiler's division, from the untouched state.
+            std::vector<void *> pointers;
+            for (auto key : k->input_keys) pointers.push_back(ctx->buffers[key].pointer);
+            for (auto key : k->output_keys) pointers.push_back(ctx->buffers[key].pointer);
+            for (void *p : k->redo.pack_device) pointers.push_back(p);
+            pointers.push_back(ctx->device_flags);
+            unsigned long long n = k->num_rays;
+            unsigned int one = 1;
+            std::vector<void *> params;
+            for (auto &p : pointers) params.push_back(&p);
+            params.push_back(&n);
+            params.push_back(&k->flagged);
+            params.push_back(&k->redo_list);
+            params.push_back(&k->redo_count);
+            params.push_back(&one);
+            GFHIP_TRY(ctx, hipModuleLaunchKernel(k->redo.function, 64, 1, 1, k->redo.low.block_size, 1, 1,
+                                                 static_cast<unsigned int> (k->redo.low.lds_bytes), ctx->stream,
+                                                 params.data(), nullptr), "hipModuleLaunchKernel(redo)");
+            GFHIP_TRY(ctx, hipMemsetAsync(k->redo_count, 0, sizeof(unsigned int), ctx->stream), "hipMemsetAsync(redo count)");
+        }
+    }
+    return 0;
+}
+
 static int launch(gfhip_kernel *k, const uint32_t steps, unsigned long long *reduce = nullptr,
                   const unsigned int *stop = nullptr) {
     gfhip_context *ctx = k->ctx;
@@ -507,6 +862,26 @@ static int launch(gfhip_kernel *k, const uint32_t steps, unsigned long long *red
     if (!k->bound) return ctx->fail("kernel arguments are not bound (gfhip_create_kernel_call)");
     if (k->num_rays == 0 || steps == 0) return 0;
     if (reduce && !k->max_function) return ctx->fail("item has no in-launch max reduction");
+    if (!k->pieces.empty()) {
+        std::pair<hipEvent_t, hipEvent_t> ev;
+        const bool timed = ctx->timing && (k->launch_count++ % ctx->timing) == 0;
+        if (timed) {
+            if (!k->free_events.empty()) {
+                ev = k->free_events.back();
+                k->free_events.pop_back();
+            } else {
+                GFHIP_TRY(ctx, hipEventCreate(&ev.first), "hipEventCreate");
+                GFHIP_TRY(ctx, hipEventCreate(&ev.second), "hipEventCreate");
+            }
+            GFHIP_TRY(ctx, hipEventRecord(ev.first, ctx->stream), "hipEventRecord");
+        }
+        if (launch_pieces(k, steps)) return 1;
+        if (timed) {
+            GFHIP_TRY(ctx, hipEventRecord(ev.second, ctx->stream), "hipEventRecord");
+            k->events.push_back(ev);
+        }
+        return 0;
+    }
 
     std::vector<void *> pointers;
     for (auto key : k->input_keys) pointers.push_back(ctx->buffers[key].pointer);
@@ -779,6 +1154,122 @@ static int converge_on_device(gfhip_kernel *k, const double tolerance, const siz
     return 0;
 }
 
+//  One launch of `<name>_batch`: `passes` passes on state kept in registers, the max of each pass folded
+//  into reduce[pass]; the setter targets as they were before the launch are saved in the undo arrays.
+static int launch_batch(gfhip_kernel *k, const unsigned int passes, const unsigned int *stop) {
+    gfhip_context *ctx = k->ctx;
+    std::vector<void *> pointers;
+    for (auto key : k->input_keys) pointers.push_back(ctx->buffers[key].pointer);
+    for (auto key : k->output_keys) pointers.push_back(ctx->buffers[key].pointer);
+    for (void *p : k->pack_device) pointers.push_back(p);
+    pointers.push_back(ctx->device_flags);
+    unsigned long long n = k->num_rays;
+    unsigned int count = passes;
+    std::vector<void *> params;
+    for (auto &p : pointers) params.push_back(&p);
+    params.push_back(&n);
+    params.push_back(&count);
+    params.push_back(&ctx->device_scalar);
+    params.push_back(&stop);
+    for (auto &u : k->undo) params.push_back(&u);
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    const bool timed = ctx->timing && (k->launch_count++ % ctx->timing) == 0;
+    if (timed) {
+        if (!k->free_events.empty()) {
+            ev = k->free_events.back();
+            k->free_events.pop_back();
+        } else {
+            GFHIP_TRY(ctx, hipEventCreate(&ev.first), "hipEventCreate");
+            GFHIP_TRY(ctx, hipEventCreate(&ev.second), "hipEventCreate");
+        }
+        GFHIP_TRY(ctx, hipEventRecord(ev.first, ctx->stream), "hipEventRecord");
+    }
+    GFHIP_TRY(ctx, hipModuleLaunchKernel(k->batch_function, k->grid, 1, 1, k->low.block_size, 1, 1,
+                                         static_cast<unsigned int> (k->low.lds_bytes), ctx->stream,
+                                         params.data(), nullptr), "hipModuleLaunchKernel(batch)");
+    if (timed) {
+        GFHIP_TRY(ctx, hipEventRecord(ev.second, ctx->stream), "hipEventRecord");
+        k->events.push_back(ev);
+    }
+    return 0;
+}
+
+//  The converge loop with several passes per launch (`<name>_batch`, codegen.hpp).  A pass of this loop
+//  only feeds the next pass of the same ray and the max the loop's test looks at, so a launch may run a
+//  few passes on state kept in registers — each pass leaving its own max — and the test (on the device,
+//  reduce.hip: converge_decide_batch_kernel) is applied to those maxima in order afterwards.  If the loop
+//  turns out to have ended before the last pass of a batch, the state of the beginning of that batch is
+//  restored from the undo arrays and the batch is redone with exactly the passes the loop ran: the same
+//  passes, iteration count, state and output as one launch per pass, at a third of the sweeps over the
+//  state.  Batches are queued ahead of the host like the single passes of converge_on_device.
+static int converge_batched(gfhip_kernel *k, const double tolerance, const size_t max_iterations,
+                            size_t *iterations_out, double *last_max) {
+    gfhip_context *ctx = k->ctx;
+    const bool f64 = k->item.dtype == GFIR_F64;
+    const size_t esize = k->item.element_size();
+    const unsigned int batch = k->low.batch;
+    if (k->undo.empty()) {
+        for (size_t s = 0; s < k->item.setters.size(); s++) {
+            void *p = nullptr;
+            GFHIP_TRY(ctx, hipMalloc(&p, k->num_rays*esize), "hipMalloc(undo)");
+            k->undo.push_back(p);
+        }
+    }
+    gfhip::converge_state &host = *ctx->host_converge;
+    host = gfhip::converge_state();
+    host.last = host.off_last = f64 ? std::numeric_limits<double>::max()
+                                    : static_cast<double> (std::numeric_limits<float>::max());
+    host.tolerance = tolerance;
+    host.limit = max_iterations;
+    GFHIP_TRY(ctx, hipMemcpyAsync(ctx->device_converge, &host, sizeof(host), hipMemcpyHostToDevice, ctx->stream),
+              "hipMemcpyAsync(converge state)");
+    GFHIP_TRY(ctx, hipMemsetAsync(ctx->device_scalar, 0, 8*sizeof(unsigned long long), ctx->stream), "hipMemsetAsync");
+    GFHIP_TRY(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");     // `host` is written again below
+    const unsigned int *stop = &ctx->device_converge->done;
+    const uint64_t first_launch = k->launch_count;
+    const size_t events_before = k->events.size();
+    size_t queued = 6;                                     // batches per host synchronisation, growing
+    for (;;) {
+        for (size_t b = 0; b < queued; b++) {
+            if (launch_batch(k, batch, stop)) return 1;
+            gfhip::launch_converge_decide_batch(f64, ctx->device_scalar, ctx->device_converge, batch, ctx->stream);
+            GFHIP_TRY(ctx, hipGetLastError(), "converge_decide launch");
+        }
+        GFHIP_TRY(ctx, hipMemcpyAsync(&host, ctx->device_converge, sizeof(host), hipMemcpyDeviceToHost, ctx->stream),
+                  "hipMemcpyAsync(converge state)");
+        GFHIP_TRY(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+        if (host.done) break;
+        if (queued < 24) queued *= 2;
+    }
+//  Launch timing: keep the event pairs of the batches that ran; the queued launches that returned at once
+//  are not launches of the item's work.
+    if (ctx->timing) {
+        const uint64_t batches = (static_cast<uint64_t> (host.passes) + host.extra + batch - 1)/batch;
+        size_t ran = 0;
+        for (uint64_t l = first_launch; l < first_launch + batches; l++) {
+            if (l % ctx->timing == 0) ran++;
+        }
+        while (k->events.size() > events_before + ran) {
+            k->free_events.push_back(k->events.back());
+            k->events.pop_back();
+        }
+    }
+    if (host.extra) {
+//  The loop ended inside the last batch: back to the state of its beginning, then only the loop's passes.
+        for (size_t s = 0; s < k->item.setters.size(); s++) {
+            void *target = ctx->buffers[k->input_keys[k->item.setters[s].input]].pointer;
+            GFHIP_TRY(ctx, hipMemcpyAsync(target, k->undo[s], k->num_rays*esize, hipMemcpyDeviceToDevice, ctx->stream),
+                      "hipMemcpyAsync(undo)");
+        }
+        if (launch_batch(k, host.batch_passes, nullptr)) return 1;
+        GFHIP_TRY(ctx, hipMemsetAsync(ctx->device_scalar, 0, 8*sizeof(unsigned long long), ctx->stream), "hipMemsetAsync");
+        GFHIP_TRY(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    }
+    if (iterations_out) *iterations_out = static_cast<size_t> (host.iterations);
+    if (last_max) *last_max = host.max_residual;
+    return 0;
+}
+
 extern "C" int gfhip_converge(gfhip_kernel *k, double tolerance, size_t max_iterations,
                               size_t *iterations, double *last_max) {
     if (!k) return 1;
@@ -793,6 +1284,8 @@ extern "C" int gfhip_converge(gfhip_kernel *k, double tolerance, size_t max_iter
     if (k->item.is_complex()) {
         status = k->item.base_is_f64() ? converge_loop_complex<double> (k, tolerance, max_iterations, &used, &residual)
                                        : converge_loop_complex<float> (k, tolerance, max_iterations, &used, &residual);
+    } else if (k->batch_function && k->num_rays > 0) {
+        status = converge_batched(k, tolerance, max_iterations, &used, &residual);
     } else if (k->max_function && k->num_rays > 0) {
         status = converge_on_device(k, tolerance, max_iterations, &used, &residual);
     } else if (k->item.dtype == GFIR_F64) {
@@ -1038,7 +1531,11 @@ extern "C" int gfhip_kernel_get_info(const gfhip_kernel *k, struct gfhip_kernel_
     info->num_tables = static_cast<uint32_t> (k->item.tables.size());
     info->num_instructions = static_cast<uint32_t> (k->item.code.size());
     info->vgprs = static_cast<uint32_t> (k->vgprs);
-    info->lds_bytes = static_cast<uint32_t> (k->lds_static + k->low.lds_bytes);
+    size_t lds = k->low.lds_bytes;
+    for (auto &piece : k->pieces) lds = std::max(lds, piece.low.lds_bytes);
+    info->lds_bytes = static_cast<uint32_t> (k->lds_static + lds);
+    info->segments = static_cast<uint32_t> (k->pieces.size());
+    info->converge_batch = k->batch_function ? k->low.batch : 0;          // segments the item runs as (0: one kernel)
     info->scratch_bytes = static_cast<uint32_t> (k->scratch);
     info->block_size = k->low.block_size;
     info->grid_size = k->grid;

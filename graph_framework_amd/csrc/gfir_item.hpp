@@ -58,6 +58,52 @@ struct item {
     }
 
 //------------------------------------------------------------------------------
+///  @brief The item as GFIR bytes (include/gfir.h), the inverse of parse().
+//------------------------------------------------------------------------------
+    std::vector<uint8_t> serialize() const {
+        std::vector<uint8_t> out;
+        auto put = [&] (const void *src, const size_t n) {
+            const uint8_t *b = static_cast<const uint8_t *> (src);
+            out.insert(out.end(), b, b + n);
+        };
+        auto padded = [] (const std::string &text) {
+            std::string t = text;
+            t.append(4 - t.size()%4, '\0');
+            return t;
+        };
+        const std::string title = padded(name);
+        gfir_header h;
+        std::memcpy(h.magic, GFIR_MAGIC, 8);
+        h.dtype = dtype;
+        h.num_inputs = static_cast<uint32_t> (symbols.size());
+        h.num_outputs = static_cast<uint32_t> (outputs.size());
+        h.num_setters = static_cast<uint32_t> (setters.size());
+        h.num_tables = static_cast<uint32_t> (tables.size());
+        h.num_instructions = static_cast<uint32_t> (code.size());
+        h.name_bytes = static_cast<uint32_t> (title.size());
+        h.flags = flags;
+        put(&h, sizeof(h));
+        put(title.data(), title.size());
+        for (auto &symbol : symbols) {
+            const std::string text = padded(symbol);
+            const uint32_t n = static_cast<uint32_t> (text.size());
+            put(&n, 4);
+            put(text.data(), n);
+        }
+        for (auto &t : tables) {
+            gfir_table_header th;
+            th.rows = t.rows;
+            th.cols = t.cols;
+            put(&th, sizeof(th));
+            put(t.data.data(), sizeof(double)*t.data.size());
+        }
+        put(code.data(), sizeof(gfir_instruction)*code.size());
+        put(outputs.data(), sizeof(uint32_t)*outputs.size());
+        put(setters.data(), sizeof(gfir_setter)*setters.size());
+        return out;
+    }
+
+//------------------------------------------------------------------------------
 ///  @brief Parse and validate a serialized work item.
 ///
 ///  @param[in]  data  Serialized bytes.

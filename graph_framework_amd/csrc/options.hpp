@@ -20,7 +20,9 @@ namespace gfhip {
 enum class division_mode {
     shared,     ///< reciprocal shared per denominator; lanes that leave the checked window redo the pass with `ieee`
     checked,    ///< `shared` + every numerator's magnitude is tracked as well (complete for tiny numerators too)
-    ieee        ///< the compiler's own division sequence for every quotient
+    ieee,       ///< the compiler's own division sequence for every quotient
+    fast        ///< NOT bit-exact, opt-in: q = n*r with the refined shared reciprocal and no residual step (<= ~1.5 ulp per quotient),
+                ///< no checks, no second body.  north_star's bound is 1e-6 relative on the trajectories; the tests hold this mode to it.
 };
 
 struct codegen_options {
@@ -40,13 +42,21 @@ struct codegen_options {
     uint32_t park_prefetch = 50;        ///< issue a reload this many nodes before its first use (< window)
     bool schedule_for_pressure = true;  ///< emit in the pressure-aware order of schedule.hpp (GFHIP_SCHEDULE=source: item order)
     int division_fixup = -1;            ///< v_div_fixup after each shared-reciprocal quotient: 1 yes, 0 no, -1 auto (GFHIP_DIV_FIXUP)
+    uint32_t converge_batch = 3;        ///< converge items: passes per launch of `<name>_batch` (state in registers between them, one max per
+                                        ///< pass; GFHIP_CONVERGE_BATCH, 1 = one launch per pass)
+    uint32_t segment_nodes = 6000;      ///< items of more records are cut into segments of about this many, each a kernel of its own
+                                        ///< (segments.hpp; GFHIP_SEGMENT_NODES, 0 = never)
+    uint32_t segments = 0;              ///< experiment: cut every item of 2000 records and more into this many segments (GFHIP_SEGMENTS)
+    size_t handover_bytes = 128u << 20; ///< the hand-over buffers of a segmented item hold one chunk of rays and at most this many
+                                        ///< bytes, so that they stay in the 256 MB Infinity Cache (GFHIP_HANDOVER_BYTES)
 
 //  Environment overrides (they change the generated text, hence the cache key).
     static codegen_options from_environment() {
         codegen_options o;
         if (const char *e = std::getenv("GFHIP_DIVISION")) {
             const std::string mode(e);
-            o.division = mode == "ieee" ? division_mode::ieee : mode == "checked" ? division_mode::checked : division_mode::shared;
+            o.division = mode == "ieee" ? division_mode::ieee : mode == "checked" ? division_mode::checked
+                       : mode == "fast" ? division_mode::fast : division_mode::shared;
         }
         if (const char *e = std::getenv("GFHIP_PARK")) {
             const std::string mode(e);
@@ -60,6 +70,11 @@ struct codegen_options {
         if (const char *e = std::getenv("GFHIP_POW")) o.pow_three_halves = std::string(e) != "libm";
         if (const char *e = std::getenv("GFHIP_WAVES_PER_SIMD")) o.waves_per_simd = static_cast<uint32_t> (std::atoi(e));
         if (const char *e = std::getenv("GFHIP_LDS_BUDGET")) o.lds_budget = static_cast<size_t> (std::atol(e));
+        if (const char *e = std::getenv("GFHIP_CONVERGE_BATCH")) o.converge_batch = static_cast<uint32_t> (std::atol(e) > 0 ? std::atol(e) : 1);
+        if (o.converge_batch > 8) o.converge_batch = 8;
+        if (const char *e = std::getenv("GFHIP_SEGMENT_NODES")) o.segment_nodes = static_cast<uint32_t> (std::atol(e));
+        if (const char *e = std::getenv("GFHIP_SEGMENTS")) o.segments = static_cast<uint32_t> (std::atol(e));
+        if (const char *e = std::getenv("GFHIP_HANDOVER_BYTES")) o.handover_bytes = static_cast<size_t> (std::atoll(e));
         return o;
     }
 };

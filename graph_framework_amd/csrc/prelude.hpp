@@ -340,6 +340,7 @@ __device__ __forceinline__ unsigned int gf_numerator_key(const double n) {
     return (static_cast<unsigned int> (__builtin_bit_cast(unsigned long long, n) >> 32) << 1) - 1u;
 }
 )";
+    const bool fast = opt.division == division_mode::fast;
     if (!f64) {
         s << R"(
 // fp32 quotients through fp64.  The exact quotient n/d of two floats that is not itself a rounding
@@ -368,6 +369,7 @@ __device__ __forceinline__ float gf_div(const float n, const float, const double
     if (f64) {
         s << (fixup ? "#define GF_FIXUP(q, d, n) __builtin_amdgcn_div_fixup(q, d, n)\n"
                     : "#define GF_FIXUP(q, d, n) (q)\n");
+        s << "#define GF_FAST_DIVISION " << (fast ? 1 : 0) << "\n";
         s << R"(
 // fp64 division as hipcc lowers it: r = rcp(d) refined by two Newton steps (shared per
 // denominator), q = n*r, e = fma(-d, q, n), q' = fma(e, r, q).
@@ -379,9 +381,13 @@ __device__ __forceinline__ double gf_rcp(const double d) {
     return __builtin_fma(r, e, r);
 }
 __device__ __forceinline__ double gf_div(const double n, const double d, const double r) {
+#if GF_FAST_DIVISION
+    return n*r;             // GFHIP_DIVISION=fast: within ~1.5 ulp of the quotient, NOT the IEEE quotient
+#else
     const double q = n*r;
     const double e = __builtin_fma(-d, q, n);
     return GF_FIXUP(__builtin_fma(e, r, q), d, n);
+#endif
 }
 // pow(x, 1.5) = x*sqrt(x) with the rounding error of the square root carried into the
 // product (s + t ~ sqrt(x) to ~100 bits), i.e. rounded once from the exact value almost

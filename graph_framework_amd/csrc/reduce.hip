@@ -130,6 +130,58 @@ __global__ void converge_decide_kernel(unsigned long long *__restrict__ reduced,
     }
 }
 
+//  The same test applied to the maxima of a batch of passes, in order (`<name>_batch`, codegen.hpp): the loop
+//  may end on any of them.  If it ends before the last pass of the batch, `extra` passes ran that the host loop
+//  would not have run; the host restores the state of the beginning of the batch and redoes `batch_passes`.
+template<typename T>
+__global__ void converge_decide_batch_kernel(unsigned long long *__restrict__ reduced, converge_state *__restrict__ state,
+                                             const unsigned int count) {
+    if (state->done) return;
+    const T tolerance = static_cast<T> (state->tolerance);
+    const T zero = static_cast<T> (0);
+    const T t = tolerance < zero ? -tolerance : tolerance;
+    for (unsigned int pass = 0; pass < count; pass++) {
+        const unsigned long long key = reduced[pass];
+        reduced[pass] = 0ull;
+        if (state->done) continue;                   // still clear the slots of the passes beyond the end
+        T value;
+        if (sizeof(T) == 8) {
+            const unsigned long long bits = (key >> 63) ? (key & 0x7FFFFFFFFFFFFFFFull) : ~key;
+            value = static_cast<T> (__longlong_as_double(static_cast<long long> (bits)));
+        } else {
+            const unsigned int k32 = static_cast<unsigned int> (key);
+            const unsigned int bits = (k32 >> 31) ? (k32 & 0x7FFFFFFFu) : ~k32;
+            value = static_cast<T> (__uint_as_float(bits));
+        }
+        const T last = static_cast<T> (state->last), off_last = static_cast<T> (state->off_last);
+        state->max_residual = static_cast<double> (value);
+        state->passes++;
+        const T a = value < zero ? -value : value;
+        const T dl = last - value, dol = off_last - value;
+        bool go = a > t && (dl < zero ? -dl : dl) > t && (dol < zero ? -dol : dol) > t;
+        if (go) {
+            go = state->iterations < state->limit;
+            state->iterations++;
+        }
+        if (go) {
+            state->last = static_cast<double> (value);
+            if (!(state->iterations%2ull)) state->off_last = static_cast<double> (value);
+        } else {
+            state->done = 1u;
+            state->batch_passes = pass + 1u;
+            state->extra = count - (pass + 1u);
+        }
+    }
+}
+
+void launch_converge_decide_batch(const bool f64, unsigned long long *reduced, void *state, const unsigned int count, hipStream_t stream) {
+    if (f64) {
+        hipLaunchKernelGGL(converge_decide_batch_kernel<double>, dim3(1), dim3(1), 0, stream, reduced, static_cast<converge_state *> (state), count);
+    } else {
+        hipLaunchKernelGGL(converge_decide_batch_kernel<float>, dim3(1), dim3(1), 0, stream, reduced, static_cast<converge_state *> (state), count);
+    }
+}
+
 void launch_converge_decide(const bool f64, unsigned long long *reduced, void *state, hipStream_t stream) {
     if (f64) {
         hipLaunchKernelGGL(converge_decide_kernel<double>, dim3(1), dim3(1), 0, stream, reduced, static_cast<converge_state *> (state));

@@ -76,6 +76,19 @@ inline item schedule_for_pressure(const item &in) {
         }
     }
 
+//  The distinct operands of every record, once (the loop below looks at every ready record at every step).
+    std::vector<uint32_t> distinct_operands(3*n, GFIR_NONE);
+    std::vector<uint8_t> distinct_count(n, 0);
+    for (size_t i = 0; i < n; i++) {
+        const gfir_instruction &c = in.code[i];
+        const uint32_t operands[3] = {c.a, c.b, c.c};
+        for (int k = 0; k < operand_count(c.op); k++) {
+            bool seen = false;
+            for (int j = 0; j < distinct_count[i]; j++) seen = seen || distinct_operands[3*i + j] == operands[k];
+            if (!seen) distinct_operands[3*i + distinct_count[i]++] = operands[k];
+        }
+    }
+
     std::set<uint32_t> ready;
     std::vector<uint32_t> stamp(n, 0);                   // emission count when the node became ready
     for (size_t i = 0; i < n; i++) {
@@ -87,16 +100,13 @@ inline item schedule_for_pressure(const item &in) {
         uint32_t best = *ready.begin();
         int best_score = 1 << 30;
         for (const uint32_t v : ready) {
-            const gfir_instruction &c = in.code[v];
-            const uint32_t operands[3] = {c.a, c.b, c.c};
-            std::set<uint32_t> distinct;
-            for (int k = 0; k < operand_count(c.op); k++) distinct.insert(operands[k]);
             int freed = 0;
-            for (auto o : distinct) {
+            for (int k = 0; k < distinct_count[v]; k++) {
+                const uint32_t o = distinct_operands[3*static_cast<size_t> (v) + k];
                 if (in.code[o].op != GFIR_CONST && consumers_left[o] == 1 && !is_root[o]) freed++;
             }
 //  Constants cost nothing; inputs become live only when first read.
-            const int grows = (c.op == GFIR_CONST) ? 0 : 1;
+            const int grows = (in.code[v].op == GFIR_CONST) ? 0 : 1;
             const int score = grows - freed;
             if (score < best_score || (score == best_score && stamp[v] > stamp[best])) {
                 best_score = score;
@@ -105,11 +115,7 @@ inline item schedule_for_pressure(const item &in) {
         }
         ready.erase(best);
         order.push_back(best);
-        const gfir_instruction &c = in.code[best];
-        const uint32_t operands[3] = {c.a, c.b, c.c};
-        std::set<uint32_t> distinct;
-        for (int k = 0; k < operand_count(c.op); k++) distinct.insert(operands[k]);
-        for (auto o : distinct) consumers_left[o]--;
+        for (int k = 0; k < distinct_count[best]; k++) consumers_left[distinct_operands[3*static_cast<size_t> (best) + k]]--;
         for (auto u : users[best]) {
             if (--pending[u] == 0) {
                 ready.insert(u);

@@ -52,6 +52,25 @@ inline table_layout layout_tables(const item &it, const codegen_options &opt) {
     parent.assign(it.tables.size(), -1);
     factor.assign(it.tables.size(), 1.0);
     if (opt.compact_tables && !it.is_complex()) {
+//  A pair of tables costs a full comparison only if it passes a two-cell test first: for to = k*from the cross
+//  products to[a]*from[b] and to[b]*from[a] agree (to 1e-5: exactness is judged in the item's precision below;
+//  a = the cell of from's largest magnitude, b = half the table further on).  With the thousands of tables of
+//  a VMEC ray step the pairs are millions, and nearly all of them end here.
+        std::vector<size_t> largest(it.tables.size(), 0);
+        for (size_t t = 0; t < it.tables.size(); t++) {
+            double best = 0.0;
+            for (size_t c = 0; c < it.tables[t].data.size(); c++) {
+                if (std::fabs(it.tables[t].data[c]) > best) { best = std::fabs(it.tables[t].data[c]); largest[t] = c; }
+            }
+        }
+        auto may_derive = [&] (const size_t from_index, const size_t to_index) -> bool {
+            const table &from = it.tables[from_index], &to = it.tables[to_index];
+            if (from.rows != to.rows || from.cols != to.cols) return false;
+            const size_t a = largest[from_index], b = (a + from.data.size()/2)%from.data.size();
+            if ((from.data[a] == 0.0) != (to.data[a] == 0.0) || (from.data[b] == 0.0) != (to.data[b] == 0.0)) return false;
+            const double left = to.data[a]*from.data[b], right = to.data[b]*from.data[a];
+            return std::fabs(left - right) <= 1.0E-5*std::fmax(std::fabs(left), std::fabs(right));
+        };
         auto derive = [&] (const table &from, const table &to, double &k_out) -> bool {
             if (from.rows != to.rows || from.cols != to.cols) return false;
             size_t arg = 0;
@@ -86,7 +105,7 @@ inline table_layout layout_tables(const item &it, const codegen_options &opt) {
         for (size_t j = 0; j < it.tables.size(); j++) {
             for (size_t i = 0; i < j; i++) {
                 double k;
-                if (derive(it.tables[i], it.tables[j], k)) {
+                if (may_derive(i, j) && derive(it.tables[i], it.tables[j], k)) {
                     parent[j] = static_cast<int> (i);
                     factor[j] = k;
                     break;
@@ -101,7 +120,7 @@ inline table_layout layout_tables(const item &it, const codegen_options &opt) {
             for (size_t i = j + 1; i < it.tables.size(); i++) {
                 if (parent[i] >= 0) continue;
                 double k;
-                if (derive(it.tables[i], it.tables[j], k)) {
+                if (may_derive(i, j) && derive(it.tables[i], it.tables[j], k)) {
                     parent[j] = static_cast<int> (i);
                     factor[j] = k;
                     break;

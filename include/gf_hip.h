@@ -193,6 +193,8 @@ struct gfhip_kernel_info {
     uint32_t vgprs, agprs, sgprs, lds_bytes, scratch_bytes;   /* from the code object, after compile */
     uint32_t block_size, grid_size; /* launch geometry for num_rays */
     uint32_t from_cache;            /* 1 if the code object came from the kernel cache */
+    uint32_t segments;              /* kernels the item runs as when it was cut into segments, else 0 */
+    uint32_t converge_batch;        /* passes per launch of gfhip_converge's loop (`<name>_batch`), 0 or 1: one launch per pass */
     uint32_t reserved;
     uint64_t source_hash;
     char     name[64];
@@ -203,6 +205,22 @@ int gfhip_kernel_get_info(const gfhip_kernel *kernel, struct gfhip_kernel_info *
  * malloc'ed, NUL-terminated string (free with gfhip_free_string) and its hash.
  * Used by __graft_entry__.build() to pre-build code objects with hipcc. */
 char *gfhip_generate_source(const void *gfir, size_t bytes, uint64_t *source_hash);
+
+/* The same for an item that runs as several kernels: items above GFHIP_SEGMENT_NODES records (default
+ * 6000; e.g. a ray step on the 86-mode VMEC equilibrium, equilibrium.hpp:1868-2330: 54 k records) are
+ * cut into consecutive segments, each lowered and cached as a translation unit of its own.  *source =
+ * the text of piece `index` (free with gfhip_free_string), or NULL past the last piece; an item that
+ * runs as one kernel has exactly one piece.  Returns non-zero on a malformed item. */
+int gfhip_generate_piece_source(const void *gfir, size_t bytes, uint32_t index, char **source, uint64_t *source_hash);
+
+/* Piece `index` of a segmented item as data, for checking the split without a device: *piece = a
+ * malloc'ed block (free with gfhip_free_string) of int32 words
+ *   { symbols S, outputs O, hand-over slots, pieces,
+ *     S x state input it reads (-1: none), S x hand-over slot it reads (-1: none),
+ *     O x hand-over slot it writes (-1: none), O x output of the item it is (-1: none) }
+ * followed by the piece as a GFIR item (include/gfir.h).  *piece stays NULL past the last piece and
+ * for items that run as one kernel. */
+int gfhip_export_piece(const void *gfir, size_t bytes, uint32_t index, void **piece, size_t *piece_bytes);
 void gfhip_free_string(char *text);
 
 /* Host side, no device: the initial conditions of the xrays command line for one shard, sample

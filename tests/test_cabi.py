@@ -360,3 +360,74 @@ def test_result_file_is_reopened_for_the_absorption_variables(tmp_path):
         assert 'DATASET "kamp" { DATATYPE H5T_IEEE_F64LE DATASPACE SIMPLE { ( 4, 6, 2 ) / ( H5S_UNLIMITED, 6, 2 ) }' in flat
         assert 'DATASET "power" { DATATYPE H5T_IEEE_F64LE DATASPACE SIMPLE { ( 4, 6, 1 ) / ( H5S_UNLIMITED, 6, 1 ) }' in flat
         assert flat.count('"DIMENSION_SCALE"') == 4
+
+
+def _run_pieces_on_the_oracle(pieces, columns):
+    """Walk the segment sequence of a split item on the CPU oracle: each piece is an ordinary GFIR item whose
+    symbols are state columns or hand-over slots and whose outputs are slots or outputs of the item; only the
+    last piece has setters, so every piece reads the state of the beginning of the pass."""
+    from oracle import gfir
+    n = columns[0].size
+    slots = [None]*pieces[0]["slots"]
+    outputs = {}
+    for piece in pieces:
+        item = gfir.Item(piece["gfir"])
+        inputs = []
+        for state, slot in zip(piece["symbol_state"], piece["symbol_slot"]):
+            assert (state >= 0) != (slot >= 0)
+            inputs.append(columns[state] if state >= 0 else slots[slot].copy())
+        outs, _ = item.run(inputs)
+        for value, slot, original in zip(outs, piece["output_slot"], piece["output_original"]):
+            assert (slot >= 0) != (original >= 0)
+            if slot >= 0:
+                slots[slot] = value
+            else:
+                outputs[original] = value
+    assert n == columns[0].size
+    return [outputs[o] for o in sorted(outputs)]
+
+
+@pytest.mark.parametrize("workload,segments", [("solver_kernel_f64", 4), ("solver_kernel_f64", 7), ("korc_step_f64", 3),
+                                               ("adaptive_rk4_loss_kernel_f64", 5), ("solver_kernel_f32", 3)])
+def test_split_items_compute_the_same_bits_on_the_oracle(lib, monkeypatch, workload, segments):
+    """csrc/segments.hpp: cutting an item into consecutive segments that hand their live values over through
+    memory changes no bit.  The pieces the lowering makes (GFHIP_SEGMENTS; the same code path cuts items above
+    GFHIP_SEGMENT_NODES records automatically) are exported as GFIR items and run one after the other on the
+    CPU oracle, against the unsplit item on the same rays: state after the pass and outputs, two passes."""
+    from graph_framework_amd.backend import export_pieces
+    from oracle import gfir
+    from conftest import random_plasma_state, STATE
+    path = os.path.join(WORKLOADS, workload + ".gfir")
+    monkeypatch.setenv("GFHIP_SEGMENTS", str(segments))
+    monkeypatch.setenv("GFHIP_SEGMENT_NODES", "0")
+    if "korc" in workload:
+        monkeypatch.setenv("GFHIP_SEGMENTS", "0")
+        monkeypatch.setenv("GFHIP_SEGMENT_NODES", "80")              # a small item: cut by size instead
+    pieces = export_pieces(path)
+    assert len(pieces) >= 3 and pieces[0]["pieces"] == len(pieces)
+    assert all(not any(s >= 0 for s in piece["output_original"]) for piece in pieces[:-1])
+    whole = gfir.Item(path)
+    real = np.float32 if workload.endswith("f32") else np.float64
+    n = 257
+    if "korc" in workload:
+        rng = np.random.default_rng(4)
+        columns = [rng.uniform(1.5, 1.9, n), rng.uniform(-0.2, 0.2, n), rng.uniform(-0.3, 0.3, n), rng.uniform(-3.0, 3.0, n),
+                   rng.uniform(3.0, 9.0, n), rng.uniform(-3.0, 3.0, n), rng.uniform(5.0, 11.0, n)]
+    else:
+        state = random_plasma_state(n, seed=9)
+        columns = [state[k] for k in STATE]
+        if "adaptive" in workload:
+            columns += [np.full(n, 1.0e-3), np.ones(n)]
+    columns = [np.ascontiguousarray(c, dtype=real) for c in columns]
+    split_columns = [c.copy() for c in columns]
+    for _ in range(2):
+        want, _ = whole.run(columns)
+        got = _run_pieces_on_the_oracle(pieces, split_columns)
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b, equal_nan=True)
+        for a, b in zip(split_columns, columns):
+            assert np.array_equal(a, b, equal_nan=True)
+    monkeypatch.delenv("GFHIP_SEGMENTS")
+    monkeypatch.setenv("GFHIP_SEGMENT_NODES", "6000")
+    assert export_pieces(path) == []                                  # by default these items run as one kernel
