@@ -215,9 +215,8 @@ struct kernel_writer {
                     const std::string from = value_at(group, static_cast<uint32_t> (parent[t]));
                     s << ind << "const real " << value_name << " = " << literal(factor[t]) << "*" << from << ";\n";
                 } else {
-                    const uint32_t pi = table_pack[t];
-                    const std::string base = (out.packs[pi].in_lds ? "lds" : "pack") + std::to_string(pi);
-                    s << ind << "const real " << value_name << " = " << base << "[" << group << " + " << table_column[t] << "u];\n";
+//  `group` points at the cell: the column is an immediate offset of the load (one address per group, not per table).
+                    s << ind << "const real " << value_name << " = " << group << "[" << table_column[t] << "u];\n";
                 }
             }
             return value_name;
@@ -350,9 +349,14 @@ struct kernel_writer {
                         const pack &p = out.packs[table_pack[c.aux]];
                         const std::string first = index_expression(c.a, c.imm[0], c.imm[1], two ? t.rows : t.cols);
                         const std::string second = two ? index_expression(c.b, c.imm[2], c.imm[3], t.cols) : std::string();
-                        s << ind << "const unsigned int " << group_name << " = (" << first;
+//  A pointer to the group's cell in its pack ([cell][table], tables.hpp): computed once, every gather of the group
+//  is then a load at an immediate offset from it (as an index added to the pack's base each table needed a 32-bit add
+//  and a 64-bit address of its own: 61 address instructions for the 27 loads of the fp32 xkorc push).
+                        const uint32_t pi = table_pack[c.aux];
+                        const std::string base = (out.packs[pi].in_lds ? "lds" : "pack") + std::to_string(pi);
+                        s << ind << "const real *const " << group_name << " = " << base << " + static_cast<size_t> ((" << first;
                         if (two) s << "*" << t.cols << "u + " << second;
-                        s << ")*" << p.stride << "u;\n";
+                        s << ")*" << p.stride << "u);\n";
                         g = groups.insert({key, group_name}).first;
                     }
 //  A derived table's value (k*parent) is defined at its first use, not here: next to the

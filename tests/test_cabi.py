@@ -48,10 +48,14 @@ def test_lowering_without_a_device(lib):
     source, source_hash = generate_source(os.path.join(WORKLOADS, "solver_kernel_f64.gfir"))
     assert "gfhip_solver_kernel" in source and source_hash != 0
     # 8 gather index groups per RK4 step (4 stages x {(r,z) cell, psi bin}) instead of 360 index expressions
-    assert len(set(re.findall(r"const unsigned int (g\d+) =", source))) == 8
+    assert len(set(re.findall(r"const real \*const (g\d+) =", source))) == 8
     # tables that are exact multiples of another are not stored: 45 psi tables -> 20, 45 profile tables -> 12
-    assert len(set(re.findall(r"= pack0\[g\d+ \+ (\d+)u\]", source))) == 20
-    assert len(set(re.findall(r"= lds1\[g\d+ \+ (\d+)u\]", source))) == 12
+    psi_groups = set(re.findall(r"const real \*const (g\d+) = pack0 \+", source))
+    profile_groups = set(re.findall(r"const real \*const (g\d+) = lds1 \+", source))
+    assert len(psi_groups) == 4 and len(profile_groups) == 4
+    loads = re.findall(r"= (g\d+)\[(\d+)u\];", source)
+    assert len({column for group, column in loads if group in psi_groups}) == 20
+    assert len({column for group, column in loads if group in profile_groups}) == 12
     # one reciprocal per distinct denominator (82), 680 divisions through it (+ the 12 index quotients)
     assert len(re.findall(r"= gf_rcp\(", source)) == 82
     assert len(re.findall(r"const real r\d+ = gf_div\(r", source)) == 680
