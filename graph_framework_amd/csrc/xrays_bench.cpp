@@ -13,7 +13,10 @@
 ///  The work items come from GFIR files (the DAGs the reference front end builds
 ///  for this case); this program needs neither the reference headers nor Python.
 ///
-///  Usage: xrays_bench <workload directory> [num_rays=100000] [num_times=1000]
+///  Usage: xrays_bench <workload directory> [num_rays=100000] [num_times=1000] [output prefix [sub_steps]]
+///  With an output prefix every device thread writes `<prefix><thread>.nc` as graph_driver/xrays.cpp does
+///  (:1054-1083): the state after the Newton solve, then every `sub_steps` (default 100) steps through
+///  solver_interface::write_step (solver.hpp:418-424) — the writer thread overlaps the following steps.
 //------------------------------------------------------------------------------
 #include <algorithm>
 #include <chrono>
@@ -56,6 +59,8 @@ int main(int argc, char **argv) {
     const std::string directory = argv[1];
     const size_t num_rays = argc > 2 ? strtoull(argv[2], nullptr, 10) : 100000;
     const size_t num_times = argc > 3 ? strtoull(argv[3], nullptr, 10) : 1000;
+    const std::string output_prefix = argc > 4 ? argv[4] : "";
+    const size_t sub_steps = argc > 5 ? strtoull(argv[5], nullptr, 10) : 100;
 
     const size_t devices = static_cast<size_t> (std::max(gfhip_max_concurrency(), 0));
     if (devices == 0) {
@@ -98,12 +103,18 @@ int main(int argc, char **argv) {
             solve.compile();
             time_compile.end_time(i);
 
+            if (!output_prefix.empty()) {
+                solve.open_result_file(output_prefix + std::to_string(i) + ".nc");
+                solve.write_step();
+            }
             time_steps.start_time(i);
             for (size_t j = 0; j < num_times; j++) {
                 solve.step();
+                if (!output_prefix.empty() && sub_steps && (j + 1)%sub_steps == 0) solve.write_step();
             }
             solve.sync_host();
             time_steps.end_time(i);
+            solve.close_result_file();
 
             final_x[i] = solve.state["x"][local_num_rays - 1];
             final_kx[i] = solve.state["kx"][local_num_rays - 1];

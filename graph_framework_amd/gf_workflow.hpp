@@ -9,7 +9,7 @@
 ///      copy_to_device, copy_to_host, check_value, get_context
 ///    gf::solver::ray_solver<T>  <- solver::solver_interface          (solver.hpp:123-430)
 ///      init(unknown, tolerance, max_iterations), compile, step, sync_host, sync_device,
-///      check_residual
+///      check_residual, write_step (result file: gf_output.hpp)
 ///  Variables are named by their symbol (the reference keys buffers by leaf_node*); a work item
 ///  arrives as the bytes of a GFIR file.  Errors follow the reference (message on stderr and
 ///  exit(1): graph_c_binding.cpp:2355, cuda_context.hpp:55-67).  Header only; link libgf_hip.so.
@@ -26,10 +26,12 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../include/gf_hip.h"
 #include "../include/gfir.h"
+#include "gf_output.hpp"
 
 namespace gf {
 
@@ -230,6 +232,10 @@ class ray_solver {
         return init;
     }
 
+    std::unique_ptr<output::result_file<T>> file;
+    std::vector<const T *> mirrors;
+    std::thread sync;
+
 public:
 ///  Host copies of the ray variables (the reference's variable nodes), input order of the kernels.
     std::map<std::string, std::vector<T>> state;
@@ -265,6 +271,41 @@ public:
     void sync_host() { for (auto &n : names) work.copy_to_host(n, state[n].data()); }      // :368-377
     void sync_device() { for (auto &n : names) work.copy_to_device(n, state[n].data()); }  // :354-363
     T check_residual(const size_t index) { return work.check_value(index, "residual"); }   // :392
+
+///  The result file of solver_interface's constructor (solver.hpp:220-226, variables created by compile,
+///  :338-346): call after compile().  The variables are bound to the context's host mirrors of the state
+///  buffers (data_set::create_variable(file, name, node, context) -> context.get_buffer, output.hpp:260-273).
+    void open_result_file(const std::string &filename) {
+        file.reset(new output::result_file<T> (filename, num_rays));
+        const std::vector<std::pair<std::string, std::string>> stored = {{"time", "t"}, {"residual", "residual"}, {"w", "w"},
+            {"x", "x"}, {"y", "y"}, {"z", "z"}, {"kx", "kx"}, {"ky", "ky"}, {"kz", "kz"}};
+        mirrors.clear();
+        for (auto &v : stored) {
+            file->create_variable(v.first);
+            const T *mirror = static_cast<const T *> (gfhip_get_host_buffer(work.get_context(), key_of(v.second), nullptr));
+            if (!mirror) {
+                std::cerr << "gfhip_get_host_buffer: " << gfhip_last_error(work.get_context()) << std::endl;
+                exit(1);
+            }
+            mirrors.push_back(mirror);
+        }
+    }
+
+///  solver_interface::write_step (solver.hpp:418-424): join the previous writer, wait for the device (which
+///  refreshes the host mirrors), write the record on a thread of its own while the next steps run.
+    void write_step() {
+        if (!file) return;
+        if (sync.joinable()) sync.join();
+        work.wait();
+        sync = std::thread([this] { file->write(mirrors); });
+    }
+
+///  End of the trace (xrays.cpp:1078-1083): the last writer is joined and the file closed.
+    void close_result_file() {
+        if (sync.joinable()) sync.join();
+        if (file) file->close();
+    }
+    ~ray_solver() { close_result_file(); }
     T newton_residual(const size_t index) { return work.check_value(index, "newton_residual"); }
     workflow::manager<T> &manager() { return work; }
 };

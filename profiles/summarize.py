@@ -74,7 +74,7 @@ def traffic(bench_path, out_path, specs):
                         "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write, "fetch_correction": 2.0,
                         "traffic_bytes_per_launch": (2.0*fetch + write)*1024.0,
                         "algorithmic_bytes_per_launch": roof["algorithmic_bytes_per_launch"], "launches_averaged": launches,
-                        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes (profiles/collect_r02.sh), one MI355X"})
+                        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes (profiles/collect_r03.sh), one MI355X"})
     with open(out_path, "w") as f:
         json.dump(entries, f, indent=1)
     for e in entries:
