@@ -91,6 +91,8 @@ enum class piece_role { none, middle, last, redo };
 struct piece_info {
     piece_role role = piece_role::none;
     std::vector<bool> output_handed_over;       ///< per output: a hand-over value (no stored-value checks apply to it)
+    std::vector<bool> symbol_after_division;    ///< per symbol: a handed-over value that depends on a quotient of an earlier segment
+                                                ///< (a zero of it stored here may carry the wrong sign, like a zero computed here)
 };
 
 //------------------------------------------------------------------------------
@@ -840,7 +842,8 @@ inline lowered lower(const item &original, const codegen_options &opt = codegen_
         const gfir_instruction &c = it.code[i];
         const uint32_t operands[3] = {c.a, c.b, c.c};
         bool dependent = c.op == GFIR_DIV;
-        divides = divides || dependent;
+        if (c.op == GFIR_INPUT && c.a < piece.symbol_after_division.size() && piece.symbol_after_division[c.a]) dependent = true;
+        divides = divides || c.op == GFIR_DIV;
         for (int k = 0; k < operand_count(c.op) && !dependent; k++) dependent = after_division[operands[k]];
         after_division[i] = dependent;
     }
@@ -850,7 +853,15 @@ inline lowered lower(const item &original, const codegen_options &opt = codegen_
     emit_prelude(s, it, opt, out.packs.size());
 //  Items without a division node need neither the checks nor the second body (their gather
 //  indices then divide by the literal scale).
-    const bool use_shared = opt.division != division_mode::ieee && divides && !generic && piece.role != piece_role::redo;
+//  A segment that stores a quotient of an EARLIER segment has a zero to look at even if it divides nothing itself.
+    bool stores_quotient = false;
+    for (auto &st : it.setters) stores_quotient = stores_quotient || after_division[st.value];
+    for (size_t o = 0; o < it.outputs.size(); o++) {
+        const bool handed_over = o < piece.output_handed_over.size() && piece.output_handed_over[o];
+        stores_quotient = stores_quotient || (!handed_over && after_division[it.outputs[o]]);
+    }
+    const bool checks_needed = divides || (piece.role != piece_role::none && stores_quotient);
+    const bool use_shared = opt.division != division_mode::ieee && checks_needed && !generic && piece.role != piece_role::redo;
 //  Entry points: `<name>` runs `steps` passes.  Small items with an output also get `<name>_max`
 //  (the same, plus the max of the last output reduced inside the launch: create_max_call) and,
 //  with a setter, `<name>_converge`, which runs the stall loop of workflow.hpp:179-205 PER RAY

@@ -293,7 +293,7 @@ static uint32_t plan_item(const gfhip::item &it, gfhip::lowered &whole, std::vec
     size_t count = 1;
     bool automatic = false;
     if (gfhip::can_split(it)) {
-        if (opt.segments > 1 && it.code.size() >= 2000) {
+        if (opt.segments > 1 && it.code.size() >= opt.segments_min_nodes && it.code.size() >= 2*opt.segments) {
             count = opt.segments;
         } else if (opt.segment_nodes && it.code.size() > opt.segment_nodes) {
             count = (it.code.size() + opt.segment_nodes - 1)/opt.segment_nodes;
@@ -313,12 +313,22 @@ static uint32_t plan_item(const gfhip::item &it, gfhip::lowered &whole, std::vec
 //  The experiment on hot items keeps the shared-reciprocal division and compiles NO IEEE function into the
 //  segments (so that they fit two waves per SIMD): lanes outside the window are redone by one more launch.
     const bool with_redo = !automatic && piece_options.division != gfhip::division_mode::ieee;
+//  Which values of the item depend on a quotient: a handed-over one keeps that mark in the segments that read it.
+    std::vector<bool> after_division(ordered.code.size(), false);
+    for (size_t i = 0; i < ordered.code.size(); i++) {
+        const gfir_instruction &c = ordered.code[i];
+        const uint32_t operands[3] = {c.a, c.b, c.c};
+        bool dependent = c.op == GFIR_DIV;
+        for (int k = 0; k < gfhip::operand_count(c.op) && !dependent; k++) dependent = after_division[operands[k]];
+        after_division[i] = dependent;
+    }
     for (size_t p = 0; p < plan.segments.size(); p++) {
         built_piece piece;
         gfhip::piece_info role;
         if (with_redo) {
             role.role = p + 1 == plan.segments.size() ? gfhip::piece_role::last : gfhip::piece_role::middle;
             for (auto slot : plan.segments[p].output_slot) role.output_handed_over.push_back(slot >= 0);
+            for (auto record : plan.segments[p].symbol_record) role.symbol_after_division.push_back(record >= 0 && after_division[record]);
         }
         piece.low = gfhip::lower(plan.segments[p].piece, piece_options, role);
         piece.plan = std::move(plan.segments[p]);

@@ -46,7 +46,8 @@ struct codegen_options {
                                         ///< pass; GFHIP_CONVERGE_BATCH, 1 = one launch per pass)
     uint32_t segment_nodes = 6000;      ///< items of more records are cut into segments of about this many, each a kernel of its own
                                         ///< (segments.hpp; GFHIP_SEGMENT_NODES, 0 = never)
-    uint32_t segments = 0;              ///< experiment: cut every item of 2000 records and more into this many segments (GFHIP_SEGMENTS)
+    uint32_t segments = 0;              ///< experiment: cut every item of `segments_min_nodes` records and more into this many segments (GFHIP_SEGMENTS)
+    uint32_t segments_min_nodes = 2000; ///< ... (GFHIP_SEGMENTS_MIN_NODES; the tests split small items to reach the redo launch)
     size_t handover_bytes = 128u << 20; ///< the hand-over buffers of a segmented item hold one chunk of rays and at most this many
                                         ///< bytes, so that they stay in the 256 MB Infinity Cache (GFHIP_HANDOVER_BYTES)
 
@@ -74,6 +75,7 @@ struct codegen_options {
         if (o.converge_batch > 8) o.converge_batch = 8;
         if (const char *e = std::getenv("GFHIP_SEGMENT_NODES")) o.segment_nodes = static_cast<uint32_t> (std::atol(e));
         if (const char *e = std::getenv("GFHIP_SEGMENTS")) o.segments = static_cast<uint32_t> (std::atol(e));
+        if (const char *e = std::getenv("GFHIP_SEGMENTS_MIN_NODES")) o.segments_min_nodes = static_cast<uint32_t> (std::atol(e));
         if (const char *e = std::getenv("GFHIP_HANDOVER_BYTES")) o.handover_bytes = static_cast<size_t> (std::atoll(e));
         return o;
     }

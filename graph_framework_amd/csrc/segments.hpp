@@ -44,6 +44,7 @@ struct segment {
     item piece;
     std::vector<int> symbol_state;          ///< per symbol of `piece`: index of the original item's input, or -1
     std::vector<int> symbol_slot;           ///< per symbol of `piece`: hand-over slot it reads, or -1
+    std::vector<int> symbol_record;         ///< per symbol of `piece`: the record of the split item whose value the slot holds, or -1
     std::vector<int> output_slot;           ///< per output of `piece`: hand-over slot it writes, or -1 (an output of the item)
     std::vector<int> output_original;       ///< per output of `piece`: index of the original item's output, or -1
 };
@@ -192,16 +193,18 @@ inline segmentation split_item(const item &it, const std::vector<size_t> &cuts) 
             piece.symbols.push_back(it.symbols[input]);
             seg.symbol_state.push_back(static_cast<int> (input));
             seg.symbol_slot.push_back(-1);
+            seg.symbol_record.push_back(-1);
             state_symbol[static_cast<int> (input)] = index;
             return index;
         };
-        auto symbol_for_slot = [&] (const int slot) -> uint32_t {
+        auto symbol_for_slot = [&] (const int slot, const uint32_t record) -> uint32_t {
             auto found = slot_symbol.find(slot);
             if (found != slot_symbol.end()) return found->second;
             const uint32_t index = static_cast<uint32_t> (piece.symbols.size());
             piece.symbols.push_back("handed over, slot " + std::to_string(slot));
             seg.symbol_state.push_back(-1);
             seg.symbol_slot.push_back(slot);
+            seg.symbol_record.push_back(static_cast<int> (record));
             slot_symbol[slot] = index;
             return index;
         };
@@ -221,7 +224,7 @@ inline segmentation split_item(const item &it, const std::vector<size_t> &cuts) 
             } else if (c.op != GFIR_CONST) {
                 fresh = gfir_instruction();
                 fresh.op = GFIR_INPUT;
-                fresh.a = symbol_for_slot(slot_of[value]);
+                fresh.a = symbol_for_slot(slot_of[value], value);
                 fresh.b = fresh.c = GFIR_NONE;
             }
             piece.code.push_back(fresh);

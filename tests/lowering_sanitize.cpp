@@ -1,6 +1,8 @@
 // Host-only driver for the GFIR parser, scheduler and lowering (no HIP runtime): built with
 // -fsanitize=address,undefined by tests/test_cabi.py and run over every exported workload and
-// over mutated items.  Usage: lowering_sanitize <file.gfir>... [--mutate seed trials file.gfir]
+// over mutated items; every item that can be split is also cut into 2..5 segments (csrc/segments.hpp), each segment
+// serialized, parsed again and lowered in the roles of a split with a redo launch.
+// Usage: lowering_sanitize <file.gfir>... [--mutate seed trials file.gfir]
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -11,6 +13,7 @@
 
 #include "../include/gfir.h"
 #include "../graph_framework_amd/csrc/codegen.hpp"
+#include "../graph_framework_amd/csrc/segments.hpp"
 
 static std::vector<char> read_file(const char *path) {
     std::ifstream f(path, std::ios::binary);
@@ -23,6 +26,29 @@ static bool lower_bytes(const std::vector<char> &bytes, uint64_t &hash) {
     if (!it.parse(bytes.data(), bytes.size(), error)) return false;
     const gfhip::lowered low = gfhip::lower(it);
     hash = low.hash;
+    if (gfhip::can_split(it) && it.code.size() >= 40 && it.code.size() < 20000) {
+        const gfhip::item ordered = gfhip::schedule_for_pressure(it);
+        for (size_t count = 2; count <= 5; count++) {
+            gfhip::segmentation plan = gfhip::split_item(ordered, gfhip::choose_cuts(ordered, count));
+            for (size_t p = 0; p < plan.segments.size(); p++) {
+                const std::vector<uint8_t> blob = plan.segments[p].piece.serialize();
+                gfhip::item again;
+                if (!again.parse(blob.data(), blob.size(), error)) {
+                    std::fprintf(stderr, "a segment does not parse: %s\n", error.c_str());
+                    std::exit(1);
+                }
+                gfhip::piece_info role;
+                role.role = p + 1 == plan.segments.size() ? gfhip::piece_role::last : gfhip::piece_role::middle;
+                for (auto slot : plan.segments[p].output_slot) role.output_handed_over.push_back(slot >= 0);
+                hash ^= gfhip::lower(again, gfhip::codegen_options(), role).hash;
+            }
+        }
+        gfhip::piece_info redo;
+        redo.role = gfhip::piece_role::redo;
+        gfhip::codegen_options plain;
+        plain.division = gfhip::division_mode::ieee;
+        hash ^= gfhip::lower(it, plain, redo).hash;
+    }
     return true;
 }
 

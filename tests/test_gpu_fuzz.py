@@ -55,11 +55,16 @@ def test_random_work_item_bit_exact(seed, dtype, inputs, nodes, outputs, setters
 
 
 @pytest.mark.parametrize("option,value", [("GFHIP_DIVISION", "checked"), ("GFHIP_DIVISION", "ieee"), ("GFHIP_SCHEDULE", "source"),
-                                          ("GFHIP_PARK", "heavy"), ("GFHIP_LDS_BUDGET", "0"), ("GFHIP_COMPACT_TABLES", "0")])
+                                          ("GFHIP_PARK", "heavy"), ("GFHIP_LDS_BUDGET", "0"), ("GFHIP_COMPACT_TABLES", "0"),
+                                          ("GFHIP_SEGMENT_NODES", "300"), ("GFHIP_SEGMENTS", "3"), ("GFHIP_CONVERGE_BATCH", "1")])
 def test_alternative_lowerings_are_bit_exact(monkeypatch, tmp_path, option, value):
-    """Every knob options.hpp still offers computes the same bits as the default lowering."""
+    """Every knob options.hpp still offers computes the same bits as the default lowering.  GFHIP_SEGMENT_NODES=300
+    cuts both items into segments by size (compiler's division), GFHIP_SEGMENTS=3 into three segments with the
+    shared-reciprocal division and a redo launch (csrc/segments.hpp)."""
     from graph_framework_amd import Context
     monkeypatch.setenv(option, value)
+    if option == "GFHIP_SEGMENTS":
+        monkeypatch.setenv("GFHIP_SEGMENTS_MIN_NODES", "100")
     monkeypatch.setenv("GFHIP_CACHE_DIR", str(tmp_path))
     for seed, dtype, nodes, rays in ((31, "f64", 2200, 777), (32, "f32", 500, 130)):
         blob, _ = gfir_random.random_item(seed, dtype, 6, nodes, 3, 4)
@@ -71,6 +76,8 @@ def test_alternative_lowerings_are_bit_exact(monkeypatch, tmp_path, option, valu
         context.compile()
         in_keys, out_keys = ["in%d" % i for i in range(6)], ["out%d" % i for i in range(3)]
         kernel.create_kernel_call(in_keys, out_keys, initial)
+        if option.startswith("GFHIP_SEGMENT"):
+            assert kernel.info().segments >= 2
         expected = [c.copy() for c in initial]
         for launch_steps in (1, 2):
             expected_out, _ = oracle_item.run(expected, steps=launch_steps)
@@ -82,3 +89,42 @@ def test_alternative_lowerings_are_bit_exact(monkeypatch, tmp_path, option, valu
                 got = context.copy_to_host(key, np.empty(rays, dtype=oracle_item.np_dtype))
                 assert np.array_equal(got, want), (option, value, key, launch_steps)
         context.close()
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_segments_with_a_redo_launch_on_the_division_edges(monkeypatch, tmp_path, dtype):
+    """csrc/segments.hpp with the redo launch where it matters: the division stress item cut into
+    three segments, on the operands of tests/test_gpu_division.py (denominators of 2^+-600, zeros and infinities of
+    both signs, infinite and overflowing numerators).  Lanes outside the window are flagged by the segment that sees
+    them, skip their stores in the last segment, line up in the redo list and are redone by the redo kernel with the
+    compiler's division: every lane bit-identical to the oracle, over several chunks of rays (the hand-over buffers hold
+    16 384 rays; 40 000 are traced) and over two passes."""
+    from graph_framework_amd import Context
+    from test_gpu_division import _operands, _same
+    monkeypatch.setenv("GFHIP_SEGMENTS", "3")
+    monkeypatch.setenv("GFHIP_SEGMENTS_MIN_NODES", "10")
+    monkeypatch.setenv("GFHIP_HANDOVER_BYTES", "1")
+    monkeypatch.setenv("GFHIP_CACHE_DIR", str(tmp_path))
+    blob = gfir_random.division_stress_item(dtype)
+    oracle_item = gfir.Item(blob)
+    columns = _operands(dtype, tiny_numerators=(dtype == "f32"))
+    repeat = 40000//columns[0].size + 1
+    columns = [np.tile(c, repeat)[:40000].copy() for c in columns]
+    rays = columns[0].size
+    context = Context(0)
+    kernel = context.add_kernel(blob, rays)
+    context.compile()
+    in_keys, out_keys = ["n0", "n1", "d0", "d1", "x"], ["q0", "q1", "q2", "q3", "mix"]
+    kernel.create_kernel_call(in_keys, out_keys, columns)
+    assert kernel.info().segments == 3
+    expected = [c.copy() for c in columns]
+    with np.errstate(all="ignore"):
+        for _ in range(2):
+            expected_out, _ = oracle_item.run(expected)
+            kernel.run(1)
+            context.wait()
+            for key, want in zip(in_keys + out_keys, expected + expected_out):
+                got = context.copy_to_host(key, np.empty(rays, dtype=oracle_item.np_dtype))
+                assert _same(got, want), key
+    assert context.flags() & 1                                       # lanes did leave the window
+    context.close()
