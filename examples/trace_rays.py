@@ -5,6 +5,7 @@ with a record every `sub_steps`, result<rank>.nc) on the MI355X backend.
 
     python examples/trace_rays.py --rays 100000 --steps 1000 --sub-steps 100 [--output /tmp/rays]
     python examples/trace_rays.py --rays 10000 --dispersion ordinary_wave --steps 20000 --sub-steps 1000 --output /tmp/rays --absorption-model weak_damping
+    python examples/trace_rays.py --equilibrium vmec --rays 20000 --steps 10 --sub-steps 2 --output /tmp/vmec_rays
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/trace_rays.py ...
 
 One process per GPU; the ensemble is split as the reference splits it over device threads; every rank
@@ -21,6 +22,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def vmec_beam(count, seed, device):
+    """A beam in the flux coordinates of the VMEC equilibrium: omega = 400, starting surfaces s in [0.3, 0.8], random
+    poloidal and toroidal angles, k pointing inwards (k_s = -40: |k| ~ 0.9 omega on these surfaces, then the Newton solve),
+    small random k_u, k_v — the ensemble of tests/golden/make_vmec_trace_golden.py at any size."""
+    import numpy as np
+    from graph_framework_amd.xrays import RaySolver
+    rng = np.random.default_rng(seed)
+    state = dict(t=np.zeros(count), w=np.full(count, 400.0), x=rng.uniform(0.3, 0.8, count), y=rng.uniform(0.0, 2.0*np.pi, count),
+                 z=rng.uniform(0.0, 2.0*np.pi, count), kx=np.full(count, -40.0), ky=rng.uniform(-2.0, 2.0, count),
+                 kz=rng.uniform(-20.0, 20.0, count))
+    return RaySolver(state, index=device, device_state=True, workload_prefix="vmec86_")
+
+
 def main():
     parser = argparse.ArgumentParser()
     parser.add_argument("--rays", type=int, default=100000, help="ensemble size over all ranks")
@@ -29,6 +43,10 @@ def main():
     parser.add_argument("--output", default=None, help="prefix of the result files (default: no output)")
     parser.add_argument("--dispersion", choices=["cold_plasma", "ordinary_wave"], default="cold_plasma",
                         help="exported combinations: cold_plasma (dt = 1e-3, xrays_bench) and ordinary_wave (dt = 1e-4, the CLI example's)")
+    parser.add_argument("--equilibrium", choices=["efit", "vmec"], default="efit",
+                        help="efit: graph_tests/efit.nc, Cartesian rays (the benchmark's); vmec: graph_tests/vmec.nc, all 86 Fourier modes, "
+                             "rays in flux coordinates (x, y, z = s, u, v; graph_driver/xrays.cpp:382), cold_plasma, dt = 1e-3 — the RK4 step "
+                             "is a 54 k-record item that runs as 10 segment kernels")
     parser.add_argument("--absorption-model", choices=["weak_damping", "root_find"], default=None,
                         help="after the trace: kamp and power into the result file (needs --output)")
     args = parser.parse_args()
@@ -41,8 +59,11 @@ def main():
     rank, world, local_rank = distributed.init()
     torch.cuda.set_device(local_rank)
     begin, end = shard_bounds(args.rays, world, rank)
-    solve = Rk4ColdPlasmaEfit(cli_distribution(end - begin, seed=rank), index=local_rank, device_state=True,
-                              dispersion=args.dispersion)
+    if args.equilibrium == "vmec":
+        solve = vmec_beam(end - begin, rank, local_rank)
+    else:
+        solve = Rk4ColdPlasmaEfit(cli_distribution(end - begin, seed=rank), index=local_rank, device_state=True,
+                                  dispersion=args.dispersion)
     residual = solve.init("kx")
     solve.compile()
     writer = TrajectoryWriter(solve, "%s%d.nc" % (args.output, rank)) if args.output else None
