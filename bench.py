@@ -255,6 +255,38 @@ def cpu_baseline(target_seconds=12.0):
     return rays*steps/seconds, cores, sample
 
 
+def cpu_baseline_korc(target_seconds=8.0):
+    """The CPU oracle timed on a bounded sample of the xkorc push: the `step` DAG in fp32 as the reference's
+    cpu_context runs it (one compiled statement per node, serial loop per thread, contiguous shards;
+    oracle/gfir_to_c.py, gcc -O2, strict IEEE), one thread per available core."""
+    import numpy as np
+    from oracle import gfir, gfir_to_c
+    from graph_framework_amd import korc as gk
+    from graph_framework_amd.xrays import workload
+    cores = available_cores()
+    particles = 4096*cores
+    start = dict(x=1.7, y=0.0, z=0.0, ux=0.0, uy=0.99, uz=0.1, gamma=0.0)
+    columns = {k: np.full(particles, start[k], dtype=np.float32) for k in gk.PARTICLE}
+    gfir.Item(workload("korc_initialize_gamma", "f32")).run([columns[k] for k in ("ux", "uy", "uz", "gamma")])
+    how = "compiled by gcc from the DAG (oracle/gfir_to_c.py)"
+    try:
+        item = gfir_to_c.CompiledItem(workload("korc_step", "f32"))
+    except Exception:
+        item = gfir.Item(workload("korc_step", "f32"))
+        how = "interpreted by oracle/gfir_interp.c"
+    ordered = [columns[k] for k in gk.PARTICLE]
+    item.run(ordered, steps=1, threads=cores)
+    steps, seconds, chunk = 0, 0.0, 8
+    while seconds < target_seconds and steps < 100000:
+        _, took = item.run(ordered, steps=chunk, threads=cores)
+        steps += chunk
+        seconds += took
+        chunk = min(chunk*2, 2048)
+    sample = ("%d particles x %d steps of the same korc `step` DAG, fp32, strict IEEE, %s, %d threads (%.1f s)"
+              % (particles, steps, how, cores, seconds))
+    return particles*steps/seconds, cores, sample
+
+
 def hbm_roofline_from(kernel, samples, units, bytes_per_unit):
     """roofline object of one kernel from a list of its HIP-event launch durations (ms)."""
     ms = sum(samples)/len(samples) if samples else 0.0
@@ -533,6 +565,9 @@ def run_rank_korc(args):
         line["all_gather_seconds"] = gather_seconds
         line["all_gather_bytes"] = total*4*len(gk.PARTICLE)
         line["all_gather_checksum"] = checksum
+    if world == 1 and not args.no_cpu_baseline:
+        rate, cores, sample = cpu_baseline_korc()
+        line["cpu_baseline"] = {"value": rate, "unit": "particle-steps/s", "cores": cores, "kind": "port", "sample": sample}
     print(json.dumps(line))
     sys.stdout.flush()
 

@@ -73,6 +73,7 @@ def test_korc_leg_over_rccl_with_a_one_rank_group():
     arrays all-gathered; identical particles, so the gathered checksum is 7 sums of n equal values."""
     line = _bench(["--workload", "korc", "--gpus", "1", "--backend", "nccl", "--force-collectives",
                    "--total-rays", "300000", "--steps", "10", "--warmup", "2", "--warmup-seconds", "0.05"])
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["unit"] == "particle-steps/s" and line["cpu_baseline"]["value"] > 1.0e6
     assert line["unit"] == "particle-steps/s" and line["dtype"] == "f32" and line["n_gpus"] == 1
     assert line["distributed"]["backend"] == "nccl"
     assert line["all_gather_bytes"] == 300000*4*7 and line["all_gather_checksum"] != 0.0
@@ -84,7 +85,8 @@ def test_korc_leg_two_ranks_on_one_gpu():
     """C5's sharded leg rehearsed on one GPU: two ranks share device 0 over gloo, 1e6+1 particles
     split 500001 + 500000 as graph_korc/xkorc.cpp:20-25 splits them; the gathered ensemble is the
     one-rank ensemble (identical particles: same checksum as the one-rank run of the same size)."""
-    arguments = ["--workload", "korc", "--total-rays", "1000001", "--steps", "12", "--warmup", "3", "--warmup-seconds", "0.0"]
+    arguments = ["--workload", "korc", "--total-rays", "1000001", "--steps", "12", "--warmup", "3", "--warmup-seconds", "0.0",
+                 "--no-cpu-baseline"]
     two = _bench(arguments + ["--gpus", "2", "--share-gpu", "--backend", "gloo"])
     one = _bench(arguments + ["--gpus", "1", "--backend", "gloo", "--force-collectives"])
     assert two["n_gpus"] == 2 and two["scaling"] == "strong"
