@@ -288,6 +288,14 @@ struct kernel_writer {
                     s << call("__builtin_fma", "gf_fma") << "(" << N(c.a) << ", " << N(c.b) << ", " << N(c.c) << ");\n";
                     break;
                 case GFIR_SQRT:
+//  Inside the checked window the compiler's 18-instruction sqrt reduces to its 9-instruction core (prelude.hpp,
+//  gf_sqrt_window): the argument joins the denominators' window check, a lane outside it takes the IEEE pass.
+                    if (shared && f64 && !generic && !fast && opt.window_sqrt) {
+                        s << ind << "dmax = __builtin_elementwise_maximum(dmax, gf_magnitude(" << N(c.a) << "));\n";
+                        s << ind << "dmin = __builtin_elementwise_minimum(dmin, gf_magnitude(" << N(c.a) << "));\n";
+                        s << ind << "const real r" << i << " = gf_sqrt_window(" << N(c.a) << ");\n";
+                        break;
+                    }
                     s << ind << "const real r" << i << " = " << call("__builtin_sqrt", "gf_sqrt") << "(" << N(c.a) << ");\n";
                     break;
                 case GFIR_POWI: {
@@ -309,6 +317,13 @@ struct kernel_writer {
                         }
                     }
                     if (f64 && !generic && opt.pow_three_halves && it.code[c.b].op == GFIR_CONST && it.code[c.b].imm[0] == 1.5) {
+                        if (shared && !fast && opt.window_sqrt) {
+//  pow(x, 1.5) of a negative x is NaN either way; of a zero or an infinity (outside the window) the IEEE pass decides.
+                            s << ind << "dmax = __builtin_elementwise_maximum(dmax, gf_magnitude(" << N(c.a) << "));\n";
+                            s << ind << "dmin = __builtin_elementwise_minimum(dmin, gf_magnitude(" << N(c.a) << "));\n";
+                            s << ind << "const real r" << i << " = gf_pow_three_halves_window(" << N(c.a) << ");\n";
+                            break;
+                        }
                         s << ind << "const real r" << i << " = gf_pow_three_halves(" << N(c.a) << ");\n";
                     } else {
                         s << ind << "const real r" << i << " = " << call("pow", "gf_pow") << "(" << N(c.a) << ", " << N(c.b) << ");\n";

@@ -389,6 +389,24 @@ __device__ __forceinline__ double gf_div(const double n, const double d, const d
     return GF_FIXUP(__builtin_fma(e, r, q), d, n);
 #endif
 }
+// sqrt(x) for x inside the window the pass checks (finite, |x| in [2^-500, 2^500]; codegen.hpp tracks the argument
+// with the denominators): hipcc lowers sqrt to  scale x by 2^256 if x < 2^-767 -> y = rsq(x) -> g = x*y, h = y/2 ->
+// one coupled Newton step on (g, h) -> two residual steps -> un-scale -> keep x if it is 0 or inf  (18 vector
+// instructions).  Inside the window the scale is 0 and the final selection takes the computed root, so the nine
+// instructions below are exactly the ones that sequence executes on such an x: the same bits.  A negative x gives
+// NaN here (rsq) as there.
+__device__ __forceinline__ double gf_sqrt_window(const double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    const double g0 = x*y;
+    const double h0 = y*0.5;
+    const double r0 = __builtin_fma(-h0, g0, 0.5);
+    const double g1 = __builtin_fma(g0, r0, g0);
+    const double h1 = __builtin_fma(h0, r0, h0);
+    const double d0 = __builtin_fma(-g1, g1, x);
+    const double g2 = __builtin_fma(d0, h1, g1);
+    const double d1 = __builtin_fma(-g2, g2, x);
+    return __builtin_fma(d1, h1, g2);
+}
 // pow(x, 1.5) = x*sqrt(x) with the rounding error of the square root carried into the
 // product (s + t ~ sqrt(x) to ~100 bits), i.e. rounded once from the exact value almost
 // always, as glibc's pow is; ocml's pow is within 1 ulp only and costs ~10x more.
@@ -398,6 +416,15 @@ __device__ __forceinline__ double gf_pow_three_halves(const double x) {
     const double p = x*s;
     const double c = __builtin_fma(x, s, -p) + x*t;
     return (x > 0.0 && x < __builtin_inf()) ? p + c : pow(x, 1.5);
+}
+// The same for an x inside the checked window and positive (a negative x: NaN, as pow(x, 1.5) gives): no selection,
+// no call.
+__device__ __forceinline__ double gf_pow_three_halves_window(const double x) {
+    const double s = gf_sqrt_window(x);
+    const double t = __builtin_fma(-s, s, x)*(0.5*__builtin_amdgcn_rcp(s));
+    const double p = x*s;
+    const double c = __builtin_fma(x, s, -p) + x*t;
+    return p + c;
 }
 )";
     }

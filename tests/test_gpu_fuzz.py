@@ -56,7 +56,8 @@ def test_random_work_item_bit_exact(seed, dtype, inputs, nodes, outputs, setters
 
 @pytest.mark.parametrize("option,value", [("GFHIP_DIVISION", "checked"), ("GFHIP_DIVISION", "ieee"), ("GFHIP_SCHEDULE", "source"),
                                           ("GFHIP_PARK", "heavy"), ("GFHIP_LDS_BUDGET", "0"), ("GFHIP_COMPACT_TABLES", "0"),
-                                          ("GFHIP_SEGMENT_NODES", "300"), ("GFHIP_SEGMENTS", "3"), ("GFHIP_CONVERGE_BATCH", "1")])
+                                          ("GFHIP_SEGMENT_NODES", "300"), ("GFHIP_SEGMENTS", "3"), ("GFHIP_CONVERGE_BATCH", "1"),
+                                          ("GFHIP_WINDOW_SQRT", "1")])
 def test_alternative_lowerings_are_bit_exact(monkeypatch, tmp_path, option, value):
     """Every knob options.hpp still offers computes the same bits as the default lowering.  GFHIP_SEGMENT_NODES=300
     cuts both items into segments by size (compiler's division), GFHIP_SEGMENTS=3 into three segments with the
