@@ -13,7 +13,7 @@ import subprocess
 from . import _lib
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-KERNEL_FLAGS = ["-O3", "-ffp-contract=off", "--offload-arch=gfx950"]
+KERNEL_FLAGS = ["-O3", "-ffp-contract=off", "-fno-slp-vectorize", "--offload-arch=gfx950"]
 
 
 def build_library(force=False):

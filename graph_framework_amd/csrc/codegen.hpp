@@ -296,6 +296,14 @@ struct kernel_writer {
                         s << ind << "const real r" << i << " = gf_sqrt_window(" << N(c.a) << ");\n";
                         break;
                     }
+//  fp32: the same for sqrtf (16 -> 9 instructions), with extremes of its own: the fp32 window of the denominators
+//  is every finite non-zero float, the compiler's sqrtf re-scales below 2^-96.
+                    if (shared && !f64 && !generic && !fast && opt.window_sqrt_f32) {
+                        s << ind << "smax = __builtin_elementwise_maximum(smax, " << N(c.a) << ");\n";
+                        s << ind << "smin = __builtin_elementwise_minimum(smin, " << N(c.a) << ");\n";
+                        s << ind << "const real r" << i << " = gf_sqrt_window(" << N(c.a) << ");\n";
+                        break;
+                    }
                     s << ind << "const real r" << i << " = " << call("__builtin_sqrt", "gf_sqrt") << "(" << N(c.a) << ");\n";
                     break;
                 case GFIR_POWI: {
@@ -625,6 +633,11 @@ struct kernel_writer {
             s << "            {\n";
             s << "                float dmax = gf_magnitude(" << literal(1.0) << "), dmin = dmax;   // extreme |denominator| of this pass\n";
             if (f64) s << "                float vmax = dmax;                                   // extreme |stored value|, |index quotient|\n";
+            bool sqrt_window = false;
+            if (!f64 && opt.window_sqrt_f32) {
+                for (auto &c : it.code) sqrt_window = sqrt_window || c.op == GFIR_SQRT;
+            }
+            if (sqrt_window) s << "                float smax = 1.0f, smin = 1.0f;                       // extreme sqrtf argument\n";
             if (f64 && !fixup) s << "                float zmin = __builtin_inff();                       // smallest |value| whose zero would be observed\n";
             if (track_numerators) s << "                unsigned int nmin = 0xFFFFFFFFu;                    // smallest non-zero |numerator| key\n";
             body(true);
@@ -649,6 +662,7 @@ struct kernel_writer {
             s << "                bad = " << (f64 ? "!(vmax < __builtin_inff()) || " : "") << "!(dmin >= gf_magnitude(" << low
               << ")) || !(dmax <= gf_magnitude(" << high << "))";
             if (track_numerators) s << " || nmin < gf_numerator_key(0x1p-450)";     // fp64 only (track_numerators)
+            if (sqrt_window) s << " || !(smin >= 0x1p-96f) || !(smax < __builtin_inff())";
             s << ";\n";
 //  With v_div_fixup in the quotients the sign of a zero is the IEEE one and stored zeros need no
 //  second look (GFHIP_DIV_FIXUP=1: for ensembles that keep exact zeros in their state, e.g. a

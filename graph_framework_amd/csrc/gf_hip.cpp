@@ -479,8 +479,8 @@ static int load_code_object(gfhip_context *ctx, const std::string &name, const g
     if (hiprtcCreateProgram(&program, low.source.c_str(), (name + ".hip").c_str(), 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
         return ctx->fail("hiprtcCreateProgram failed");
     }
-    const char *options[] = {"-O3", "-ffp-contract=off", "--offload-arch=gfx950"};
-    const hiprtcResult result = hiprtcCompileProgram(program, 3, options);
+    const char *options[] = {"-O3", "-ffp-contract=off", "-fno-slp-vectorize", "--offload-arch=gfx950"};
+    const hiprtcResult result = hiprtcCompileProgram(program, 4, options);
     if (result != HIPRTC_SUCCESS) {
         size_t log_size = 0;
         hiprtcGetProgramLogSize(program, &log_size);

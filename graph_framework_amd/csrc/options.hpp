@@ -33,8 +33,9 @@ struct codegen_options {
     bool pow_three_halves = true;       ///< fp64 pow(x, 1.5) as a compensated x*sqrt(x) (GFHIP_POW=libm: ocml's pow)
     bool window_sqrt = false;           ///< fp64 sqrt and pow(x, 1.5) inside the checked window as the 9-instruction core of the compiler's
                                         ///< 18-instruction sqrt (same bits, GFHIP_WINDOW_SQRT=1).  Measured on the RK4 kernel: 809 fewer static
-                                        ///< and ~200 fewer executed vector instructions per pass, 84 more AGPR copies, 1.5 % SLOWER (2.077 vs
-                                        ///< 2.045 ms at 1e7 rays): off by default
+                                        ///< but 2 % MORE executed vector instructions per pass (SQ_INSTS_VALU), 84 more AGPR copies, 1.5 %
+                                        ///< SLOWER (2.077 vs 2.045 ms at 1e7 rays): off by default
+    bool window_sqrt_f32 = true;        ///< the same for sqrtf in fp32 items (16 -> 9 instructions, GFHIP_WINDOW_SQRT_F32=0 turns it off)
     int nontemporal = -1;               ///< nt hint on the state loads and stores: -1 = items of 100 nodes and more (measured: xkorc push
                                         ///< -5.5 %, Newton item -2.7 % at 1e7 elements, neutral at 1e6; items that only stream lose),
                                         ///< 0 = never, 1 = always, 2 = stores only, 3 = loads only (GFHIP_NONTEMPORAL)
@@ -74,6 +75,7 @@ struct codegen_options {
         if (const char *e = std::getenv("GFHIP_COMPACT_TABLES")) o.compact_tables = std::string(e) != "0";
         if (const char *e = std::getenv("GFHIP_POW")) o.pow_three_halves = std::string(e) != "libm";
         if (const char *e = std::getenv("GFHIP_WINDOW_SQRT")) o.window_sqrt = std::string(e) == "1";
+        if (const char *e = std::getenv("GFHIP_WINDOW_SQRT_F32")) o.window_sqrt_f32 = std::string(e) == "1";
         if (const char *e = std::getenv("GFHIP_WAVES_PER_SIMD")) o.waves_per_simd = static_cast<uint32_t> (std::atoi(e));
         if (const char *e = std::getenv("GFHIP_LDS_BUDGET")) o.lds_budget = static_cast<size_t> (std::atol(e));
         if (const char *e = std::getenv("GFHIP_CONVERGE_BATCH")) o.converge_batch = static_cast<uint32_t> (std::atol(e) > 0 ? std::atol(e) : 1);
@@ -97,7 +99,7 @@ inline uint64_t fnv1a(const std::string &s) {
 
 ///  Flags the lowering relies on; part of the cache key.
 inline const char *compile_flags() {
-    return "-O3 -ffp-contract=off --offload-arch=gfx950";
+    return "-O3 -ffp-contract=off -fno-slp-vectorize --offload-arch=gfx950";
 }
 
 }  // namespace gfhip

@@ -348,18 +348,29 @@ __device__ __forceinline__ unsigned int gf_numerator_key(const double n) {
 // significant bits M) is at least 1/(M*D) > 2^-49 of its own size away from it (n 2^k - M d is a
 // non-zero integer for 24-bit n, d), subnormal and overflowing results included; a double within
 // 2^-51 of the quotient therefore rounds to the IEEE fp32 quotient, sign of a zero included.
-// r = rcp(d) in fp64 refined by two Newton steps (shared per denominator: 6 instructions),
-// q = float(double(n)*r) (3 per quotient) — 183 -> 156 instructions for the 30 divisions of the
-// xkorc push, and no condition on the numerator, the quotient or a stored zero is left to check:
-// only that every denominator is finite and non-zero (the Newton steps turn rcp(0) = inf and
-// rcp(inf) = 0 into NaN).
+// r = rcp(d) in fp64 refined by one cubic step (e = 1 - d r, r' = r (1 + e + e^2): |e| <= 2^-22 from
+// v_rcp_f64 leaves e^3 < 2^-66, the two roundings 2^-52; shared per denominator: 5 instructions),
+// q = float(double(n)*r) (3 per quotient) — and no condition on the numerator, the quotient or a
+// stored zero is left to check: only that every denominator is finite and non-zero (the step turns
+// rcp(0) = inf and rcp(inf) = 0 into NaN).
 __device__ __forceinline__ double gf_rcp(const float d) {
     const double wide = d;
-    double r = __builtin_amdgcn_rcp(wide);
-    double e = __builtin_fma(-wide, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-wide, r, 1.0);
-    return __builtin_fma(r, e, r);
+    const double r = __builtin_amdgcn_rcp(wide);
+    const double e = __builtin_fma(-wide, r, 1.0);
+    return __builtin_fma(r, __builtin_fma(e, e, e), r);
+}
+// sqrtf(x) for a finite x >= 2^-96: the compiler's sqrtf scales arguments below 2^-96 by 2^32, takes v_sqrt_f32
+// (1 ulp), tests its two neighbours with one fma each, un-scales and keeps a zero or an infinity (16 vector
+// instructions); at and above 2^-96 the scale is 1 and the selection takes the root, so these nine give the same
+// bits (the correctly rounded root).  codegen.hpp tracks the argument's extremes; a negative x is NaN here as there.
+__device__ __forceinline__ float gf_sqrt_window(const float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float below = __builtin_bit_cast(float, __builtin_bit_cast(int, s) - 1);
+    const float above = __builtin_bit_cast(float, __builtin_bit_cast(int, s) + 1);
+    const float e_below = __builtin_fmaf(-below, s, x);
+    const float e_above = __builtin_fmaf(-above, s, x);
+    const float t = e_below <= 0.0f ? below : s;
+    return e_above > 0.0f ? above : t;
 }
 __device__ __forceinline__ float gf_div(const float n, const float, const double r) {
     return static_cast<float> (static_cast<double> (n)*r);
