@@ -51,6 +51,7 @@
 #include <tuple>
 #include <vector>
 
+#include "asm_body.hpp"
 #include "gfir_item.hpp"
 #include "options.hpp"
 #include "parking.hpp"
@@ -90,6 +91,7 @@ enum class piece_role { none, middle, last, redo };
 
 struct piece_info {
     piece_role role = piece_role::none;
+    bool scheduled = false;                     ///< the piece arrives in emission order (gf_hip.cpp cut it from the scheduled item)
     std::vector<bool> output_handed_over;       ///< per output: a hand-over value (no stored-value checks apply to it)
     std::vector<bool> symbol_after_division;    ///< per symbol: a handed-over value that depends on a quotient of an earlier segment
                                                 ///< (a zero of it stored here may carry the wrong sign, like a zero computed here)
@@ -113,6 +115,7 @@ struct kernel_writer {
     const bool use_shared;                          ///< shared-reciprocal division with the IEEE second body
     const std::vector<bool> &after_division;        ///< node depends on the result of a division
     const piece_info &piece;                        ///< role within a segmented item with a redo launch
+    const std::string &asm_statement;               ///< not empty: the shared-reciprocal body as one assembly statement (asm_body.hpp)
 
     const bool f64 = it.base_is_f64();
     const bool cx = it.is_complex();                ///< values are gf_complex (prelude.hpp)
@@ -534,6 +537,19 @@ struct kernel_writer {
                 offset += (count*esize + 15)/16*16;
             }
             s << "    __syncthreads();\n";
+            if (!asm_statement.empty()) {
+//  The assembly body addresses LDS itself: the staged packs' bases and the lane's slot 0 as 32-bit LDS addresses.
+                size_t base = 0;
+                for (size_t p = 0; p < out.packs.size(); p++) {
+                    if (!out.packs[p].in_lds) continue;
+                    s << "    park_t *lds_address" << p << " = (park_t *)(lds_raw + " << base << ");\n";
+                    base += (out.packs[p].elements()*esize + 15)/16*16;
+                }
+                const uint32_t per_base = 65536u/(out.block_size*8u);
+                for (uint32_t k = 0; k*per_base < park_slots; k++) {
+                    s << "    park_t *park" << k << " = (park_t *)(lds_raw + " << park_offset + static_cast<size_t> (k)*65536u << ") + threadIdx.x;\n";
+                }
+            } else
             if (park_slots) {
 //  Explicit LDS address space so the accesses stay ds_write_b64/ds_read_b64.
 //  Two laundered copies of the same LDS pointer: the compiler cannot prove that a read through
@@ -640,7 +656,7 @@ struct kernel_writer {
             if (sqrt_window) s << "                float smax = 1.0f, smin = 1.0f;                       // extreme sqrtf argument\n";
             if (f64 && !fixup) s << "                float zmin = __builtin_inff();                       // smallest |value| whose zero would be observed\n";
             if (track_numerators) s << "                unsigned int nmin = 0xFFFFFFFFu;                    // smallest non-zero |numerator| key\n";
-            body(true);
+            if (asm_statement.empty()) body(true); else s << asm_statement;
 //  The finite checks run on the same fp32 image as the window check (a non-finite value, or a
 //  double of 2^1017 and more, reads as a float NaN/infinity and fails the comparison): half a
 //  v_maximum3_f32 per value.
@@ -827,7 +843,9 @@ struct kernel_writer {
 inline lowered lower(const item &original, const codegen_options &opt = codegen_options::from_environment(),
                      const piece_info &piece = piece_info()) {
     item scheduled;
-    if (opt.schedule_for_pressure) {
+//  (the assembly body keeps the order of a piece that is already in emission order: its annotations number the
+//  records of the piece that gfhip_export_piece hands out, tests/asm_symbolic.py)
+    if (opt.schedule_for_pressure && !(opt.asm_body && piece.scheduled)) {
         scheduled = schedule_for_pressure(original);
     }
     const item &it = scheduled.code.empty() ? original : scheduled;
@@ -856,8 +874,28 @@ inline lowered lower(const item &original, const codegen_options &opt = codegen_
     const bool generic = it.is_complex() || it.safe_math() || it.has_random();
     codegen_options plain = opt;
     if (generic) plain.park_in_lds = false;
+//  The body as assembly (asm_body.hpp): only as the `last` piece of an item whose out-of-window lanes are redone by a
+//  separate launch — an IEEE function compiled into the kernel would claim registers beyond the 256 the pool ends at.
+    asm_body_text assembly;
+    const bool divides_at_all = std::any_of(it.code.begin(), it.code.end(), [] (const gfir_instruction &c) { return c.op == GFIR_DIV; });
+    if (opt.asm_body && piece.role == piece_role::last && !generic && divides_at_all && opt.division == division_mode::shared &&
+        it.code.size() >= opt.asm_min_nodes) {
+        const size_t per_block = 160u*1024u/opt.asm_waves;  // a workgroup of 256 lanes is one wave per SIMD of its CU
+        const uint32_t slot_limit = lds_used < per_block ? static_cast<uint32_t> ((per_block - lds_used)/(static_cast<size_t> (opt.block_size)*esize)) : 0;
+        asm_body_writer writer(it, opt, out.packs, parent, factor, table_pack, table_column, opt.block_size, slot_limit);
+        assembly = writer.write();
+        if (std::getenv("GFHIP_ASM_REPORT")) {
+            std::fprintf(stderr, "assembly body of %s: %s; %zu vector, %zu scalar, %zu table loads, %zu LDS reads, %zu LDS writes, %zu waits, %u slots\n",
+                         it.name.c_str(), assembly.ok ? "ok" : assembly.why.c_str(), assembly.vector, assembly.scalar, assembly.loads,
+                         assembly.lds_reads, assembly.lds_writes, assembly.waits, assembly.slots);
+        }
+    }
+    if (assembly.ok) plain.park_in_lds = false;
     uint32_t park_slots = 0;
-    const std::vector<park_plan> plan = plan_parking(it, plain, lds_used, esize, park_slots);
+    const std::vector<park_plan> plan = plain.park_in_lds && plain.park_capacity && piece.role != piece_role::redo
+                                      ? plan_parking_belady(it, plain, lds_used, esize, park_slots)
+                                      : plan_parking(it, plain, lds_used, esize, park_slots);
+    if (assembly.ok) park_slots = assembly.slots;
     const size_t park_offset = lds_used;
     lds_used += static_cast<size_t> (park_slots)*opt.block_size*esize;
     out.lds_bytes = lds_used;
@@ -903,9 +941,12 @@ inline lowered lower(const item &original, const codegen_options &opt = codegen_
     out.has_converge = out.has_max && !it.setters.empty();
     codegen_options resolved = opt;
     if (resolved.nontemporal < 0) resolved.nontemporal = it.code.size() >= 100 ? 1 : 0;
+    const std::string no_assembly;
+    const bool as_assembly = assembly.ok && use_shared;
+    if (as_assembly) resolved.waves_per_simd = opt.asm_waves;
     kernel_writer writer{s, it, resolved, out, parent, factor, table_pack, table_column, plan, lds_used, park_offset, park_slots,
-                         use_shared, after_division, piece};
-    if (park_slots) s << "typedef __attribute__((address_space(3))) real park_t;\n";
+                         use_shared, after_division, piece, as_assembly ? assembly.statement : no_assembly};
+    if (park_slots || as_assembly) s << "typedef __attribute__((address_space(3))) real park_t;\n";
     if (use_shared && piece.role == piece_role::none && opt.division != division_mode::fast) writer.ieee_function();
     writer.kernel(entry::plain);
     if (out.has_max) writer.kernel(entry::max);

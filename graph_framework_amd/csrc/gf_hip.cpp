@@ -293,20 +293,35 @@ static uint32_t plan_item(const gfhip::item &it, gfhip::lowered &whole, std::vec
     size_t count = 1;
     bool automatic = false;
     if (gfhip::can_split(it)) {
-        if (opt.segments > 1 && it.code.size() >= opt.segments_min_nodes && it.code.size() >= 2*opt.segments) {
+//  GFHIP_SEGMENTS=1: the item stays one kernel, but its lanes outside the window are redone by the redo launch
+//  instead of an IEEE function compiled into it (whose registers the kernel would have to reserve).
+        if (opt.segments >= 1 && it.code.size() >= opt.segments_min_nodes && it.code.size() >= 2*opt.segments) {
             count = opt.segments;
         } else if (opt.segment_nodes && it.code.size() > opt.segment_nodes) {
             count = (it.code.size() + opt.segment_nodes - 1)/opt.segment_nodes;
             automatic = true;
         }
     }
-    if (count < 2) {
+//  GFHIP_ASM=1: the same one-kernel form for the items the assembly body takes (asm_body.hpp).
+    bool as_assembly = opt.asm_body && count < 2 && opt.segments == 0 && opt.schedule_for_pressure && gfhip::can_split(it) &&
+                       it.code.size() >= opt.asm_min_nodes && opt.division == gfhip::division_mode::shared &&
+                       gfhip::asm_body_writer::why_not(it, opt).empty();
+    gfhip::item ordered;
+    if (as_assembly) {
+//  ... if its values fit the register pool and the LDS slots in some emission order (lower() writes the statement of the
+//  piece below; here the same writer is asked whether it can).
+        ordered = gfhip::schedule_for_assembly(it, opt);
+        as_assembly = gfhip::assembly_fits(ordered, opt);
+    }
+    if (count < 2 && opt.segments != 1 && !as_assembly) {
         whole = gfhip::lower(it, opt);
         return 0;
     }
 //  Cut in the pressure-aware emission order where that is affordable (schedule.hpp), else in the order given.
-    const gfhip::item ordered = opt.schedule_for_pressure ? gfhip::schedule_for_pressure(it) : it;
+    if (!as_assembly) ordered = opt.schedule_for_pressure ? gfhip::schedule_for_pressure(it) : it;
     gfhip::segmentation plan = gfhip::split_item(ordered, gfhip::choose_cuts(ordered, count));
+//  A one-kernel item keeps its name (profiles show gfhip_<name> and gfhip_<name>_redo).
+    if (plan.segments.size() == 1) plan.segments[0].piece.name = it.name;
     gfhip::codegen_options piece_options = opt;
 //  Very large items are off the hot path: the compiler's division, no checks, no second body.
     if (automatic) piece_options.division = gfhip::division_mode::ieee;
@@ -325,6 +340,7 @@ static uint32_t plan_item(const gfhip::item &it, gfhip::lowered &whole, std::vec
     for (size_t p = 0; p < plan.segments.size(); p++) {
         built_piece piece;
         gfhip::piece_info role;
+        role.scheduled = opt.schedule_for_pressure;
         if (with_redo) {
             role.role = p + 1 == plan.segments.size() ? gfhip::piece_role::last : gfhip::piece_role::middle;
             for (auto slot : plan.segments[p].output_slot) role.output_handed_over.push_back(slot >= 0);

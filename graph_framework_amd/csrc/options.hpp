@@ -45,6 +45,7 @@ struct codegen_options {
     uint32_t park_window = 100;         ///< ... uses closer than this share one reload
     uint32_t park_max_slots = 32;       ///< LDS slots of block_size elements each
     uint32_t park_prefetch = 50;        ///< issue a reload this many nodes before its first use (< window)
+    uint32_t park_capacity = 0;         ///< > 0: parking planned by a Belady replay with this many fp64 values in registers (GFHIP_PARK_CAPACITY)
     bool schedule_for_pressure = true;  ///< emit in the pressure-aware order of schedule.hpp (GFHIP_SCHEDULE=source: item order)
     int division_fixup = -1;            ///< v_div_fixup after each shared-reciprocal quotient: 1 yes, 0 no, -1 auto (GFHIP_DIV_FIXUP)
     uint32_t converge_batch = 3;        ///< converge items: passes per launch of `<name>_batch` (state in registers between them, one max per
@@ -53,6 +54,16 @@ struct codegen_options {
                                         ///< (segments.hpp; GFHIP_SEGMENT_NODES, 0 = never)
     uint32_t segments = 0;              ///< experiment: cut every item of `segments_min_nodes` records and more into this many segments (GFHIP_SEGMENTS)
     uint32_t segments_min_nodes = 2000; ///< ... (GFHIP_SEGMENTS_MIN_NODES; the tests split small items to reach the redo launch)
+    bool asm_body = true;               ///< fp64 items of `asm_min_nodes` records and more: the body of a pass as gfx950 assembly with a register
+                                        ///< assignment of its own (asm_body.hpp; two waves per SIMD, no AGPR copies; GFHIP_ASM=0: the compiled
+                                        ///< body).  RK4 item, 1e7 rays: 1.814 ms per step against 2.043 ms
+    uint32_t asm_waves = 2;             ///< ... waves per SIMD the kernel is built for: 2 leaves each workgroup 80 KB of LDS (40 slots) (GFHIP_ASM_WAVES)
+    uint32_t asm_schedule_tries = 64;   ///< ... tie-breaks of the list schedule tried for the order that needs the fewest LDS slots (GFHIP_ASM_TRIES)
+    uint32_t asm_min_nodes = 1000;      ///< ... (GFHIP_ASM_MIN_NODES)
+    uint32_t asm_pool_lo = 40;          ///< first VGPR of the assembly body's pool; the compiler keeps v0..v(lo-1) (GFHIP_ASM_POOL_LO)
+    uint32_t asm_load_ahead = 96;       ///< table loads are issued this many nodes ahead of their first use (GFHIP_ASM_LOAD_AHEAD) ...
+    uint32_t asm_reload_ahead = 24;     ///< ... LDS reads (values sent out of the registers, LDS-staged tables) this many (GFHIP_ASM_RELOAD_AHEAD).
+                                        ///< Measured (profiles/r03_asm_sweep.jsonl): 0/0 2.19 ms, 24/6 1.88, 48/12 1.85, 96/24 1.82; pool from v48: 1.83
     size_t handover_bytes = 128u << 20; ///< the hand-over buffers of a segmented item hold one chunk of rays and at most this many
                                         ///< bytes, so that they stay in the 256 MB Infinity Cache (GFHIP_HANDOVER_BYTES)
 
@@ -74,6 +85,15 @@ struct codegen_options {
         if (const char *e = std::getenv("GFHIP_NONTEMPORAL")) o.nontemporal = std::atoi(e);
         if (const char *e = std::getenv("GFHIP_COMPACT_TABLES")) o.compact_tables = std::string(e) != "0";
         if (const char *e = std::getenv("GFHIP_POW")) o.pow_three_halves = std::string(e) != "libm";
+        if (const char *e = std::getenv("GFHIP_PARK_CAPACITY")) o.park_capacity = static_cast<uint32_t> (std::atoi(e));
+        if (const char *e = std::getenv("GFHIP_PARK_PREFETCH")) o.park_prefetch = static_cast<uint32_t> (std::atoi(e));
+        if (const char *e = std::getenv("GFHIP_ASM")) o.asm_body = std::string(e) != "0";
+        if (const char *e = std::getenv("GFHIP_ASM_WAVES")) o.asm_waves = static_cast<uint32_t> (std::atoi(e)) == 2 ? 2 : 1;
+        if (const char *e = std::getenv("GFHIP_ASM_TRIES")) o.asm_schedule_tries = static_cast<uint32_t> (std::atoi(e));
+        if (const char *e = std::getenv("GFHIP_ASM_MIN_NODES")) o.asm_min_nodes = static_cast<uint32_t> (std::atoi(e));
+        if (const char *e = std::getenv("GFHIP_ASM_POOL_LO")) o.asm_pool_lo = static_cast<uint32_t> (std::atoi(e));
+        if (const char *e = std::getenv("GFHIP_ASM_LOAD_AHEAD")) o.asm_load_ahead = static_cast<uint32_t> (std::atoi(e));
+        if (const char *e = std::getenv("GFHIP_ASM_RELOAD_AHEAD")) o.asm_reload_ahead = static_cast<uint32_t> (std::atoi(e));
         if (const char *e = std::getenv("GFHIP_WINDOW_SQRT")) o.window_sqrt = std::string(e) == "1";
         if (const char *e = std::getenv("GFHIP_WINDOW_SQRT_F32")) o.window_sqrt_f32 = std::string(e) == "1";
         if (const char *e = std::getenv("GFHIP_WAVES_PER_SIMD")) o.waves_per_simd = static_cast<uint32_t> (std::atoi(e));

@@ -127,6 +127,77 @@ inline item schedule_for_pressure(const item &in) {
     return reorder(in, order);
 }
 
+///  The same greedy list schedule with its ties (equal score, equal age) broken by a seeded generator.  The peak
+///  number of live values varies by a factor of TWO between tie-breaks on the RK4 item (the LDS slots its assembly
+///  body needs: 19 to 113 over a hundred seeds), which is what asm_body.hpp's schedule_for_assembly searches.
+inline std::vector<uint32_t> list_schedule(const item &in, const uint32_t seed) {
+    const size_t n = in.code.size();
+    uint64_t state = 0x9E3779B97F4A7C15ull*(seed + 1u);
+    auto next = [&state] () {                            // splitmix64: the same sequence on every platform
+        uint64_t z = (state += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30))*0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27))*0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    };
+    std::vector<std::vector<uint32_t>> users(n);
+    std::vector<uint32_t> pending(n, 0), consumers_left(n, 0);
+    std::vector<bool> is_root(n, false);
+    for (auto &s : in.setters) is_root[s.value] = true;
+    for (auto o : in.outputs) is_root[o] = true;
+    std::vector<uint32_t> distinct_operands(3*n, GFIR_NONE);
+    std::vector<uint8_t> distinct_count(n, 0);
+    for (size_t i = 0; i < n; i++) {
+        const gfir_instruction &c = in.code[i];
+        const uint32_t operands[3] = {c.a, c.b, c.c};
+        for (int k = 0; k < operand_count(c.op); k++) {
+            bool seen = false;
+            for (int j = 0; j < distinct_count[i]; j++) seen = seen || distinct_operands[3*i + j] == operands[k];
+            if (!seen) distinct_operands[3*i + distinct_count[i]++] = operands[k];
+        }
+        pending[i] = distinct_count[i];
+        for (int k = 0; k < distinct_count[i]; k++) {
+            users[distinct_operands[3*i + k]].push_back(static_cast<uint32_t> (i));
+            consumers_left[distinct_operands[3*i + k]]++;
+        }
+    }
+    std::set<uint32_t> ready;
+    std::vector<uint32_t> stamp(n, 0), order, best;
+    for (size_t i = 0; i < n; i++) {
+        if (pending[i] == 0) ready.insert(static_cast<uint32_t> (i));
+    }
+    order.reserve(n);
+    while (!ready.empty()) {
+        best.clear();
+        int best_score = 1 << 30;
+        uint32_t best_stamp = 0;
+        for (const uint32_t v : ready) {
+            int freed = 0;
+            for (int k = 0; k < distinct_count[v]; k++) {
+                const uint32_t o = distinct_operands[3*static_cast<size_t> (v) + k];
+                if (in.code[o].op != GFIR_CONST && consumers_left[o] == 1 && !is_root[o]) freed++;
+            }
+            const int score = (in.code[v].op == GFIR_CONST ? 0 : 1) - freed;
+            if (score < best_score || (score == best_score && stamp[v] > best_stamp)) {
+                best_score = score;
+                best_stamp = stamp[v];
+                best.clear();
+            }
+            if (score == best_score && stamp[v] == best_stamp) best.push_back(v);
+        }
+        const uint32_t pick = best[static_cast<size_t> (next()%best.size())];
+        ready.erase(pick);
+        order.push_back(pick);
+        for (int k = 0; k < distinct_count[pick]; k++) consumers_left[distinct_operands[3*static_cast<size_t> (pick) + k]]--;
+        for (auto u : users[pick]) {
+            if (--pending[u] == 0) {
+                ready.insert(u);
+                stamp[u] = static_cast<uint32_t> (order.size());
+            }
+        }
+    }
+    return order;
+}
+
 }  // namespace gfhip
 
 #endif /* gfhip_schedule_hpp */

@@ -43,8 +43,9 @@ def test_no_device_reports_cleanly(lib):
         Context(0)
 
 
-def test_lowering_without_a_device(lib):
+def test_lowering_without_a_device(lib, monkeypatch):
     from graph_framework_amd import generate_source
+    monkeypatch.setenv("GFHIP_ASM", "0")                 # the compiled body (the default is csrc/asm_body.hpp, below)
     source, source_hash = generate_source(os.path.join(WORKLOADS, "solver_kernel_f64.gfir"))
     assert "gfhip_solver_kernel" in source and source_hash != 0
     # 8 gather index groups per RK4 step (4 stages x {(r,z) cell, psi bin}) instead of 360 index expressions
@@ -67,6 +68,28 @@ def test_lowering_without_a_device(lib):
     assert again == source and again_hash == source_hash
 
 
+def test_default_lowering_of_the_rk4_item_is_the_assembly_body(lib):
+    """solver_kernel by default: one kernel whose pass is an assembly statement (two waves per SIMD, 256 registers, no
+    IEEE function inside) plus the redo kernel with the compiler's division for the lanes that leave the window."""
+    from graph_framework_amd.backend import generate_piece_sources
+    pieces = generate_piece_sources(os.path.join(WORKLOADS, "solver_kernel_f64.gfir"))
+    assert len(pieces) == 2
+    kernel, redo = pieces[0][0], pieces[1][0]
+    assert "__launch_bounds__(256, 2)\ngfhip_solver_kernel(" in kernel and "gfhip_solver_kernel_redo(" in redo
+    assert "_ieee(" not in kernel and "redo_list" in kernel
+    statement = kernel[kernel.index("asm volatile(\n", kernel.index("float dmax")):]
+    assert len(re.findall(r"; def g\d+ ", statement)) == 8                     # the 8 cells of a step
+    assert len(re.findall(r"v_rcp_f64_e32 .*; def|v_fma_f64 .*; def q\d+", statement)) == 82      # one reciprocal per denominator
+    assert len(re.findall(r"v_rcp_f64_e32", statement)) == 82 + 4              # ... and the four pow(x, 1.5)
+    assert len(re.findall(r"v_rsq_f64_e32", statement)) == 11 + 4
+    assert 70 <= len(re.findall(r"global_load_dwordx2", statement)) <= 100     # 20 psi columns x 4 stages, a few loaded twice
+    assert "v_accvgpr" not in statement and "scratch_" not in statement
+    vector = len(re.findall(r'^\s*"v_', statement, re.M))
+    assert vector < 6000                                                        # hipcc: ~6430 for the same pass
+    assert len(re.findall(r"const real r\d+ = r\d+(?:p\d+)?/r\d+(?:p\d+)?;", redo)) == 680
+    assert generate_piece_sources(os.path.join(WORKLOADS, "solver_kernel_f64.gfir")) == pieces
+
+
 def test_malformed_items_are_rejected(lib):
     from graph_framework_amd import generate_source, GfHipError
     with open(os.path.join(WORKLOADS, "korc_initialize_gamma_f64.gfir"), "rb") as f:
@@ -82,11 +105,13 @@ def test_malformed_items_are_rejected(lib):
         generate_source(bytes(corrupt))
 
 
-def test_table_compaction_is_exact():
+def test_table_compaction_is_exact(monkeypatch):
     """Every table the lowering derives as k*parent must equal the exported table bit for bit."""
     import struct
     from graph_framework_amd import generate_source
     path = os.path.join(WORKLOADS, "solver_kernel_f64.gfir")
+    assembly, _ = generate_source(path)
+    monkeypatch.setenv("GFHIP_ASM", "0")
     source, _ = generate_source(path)
     data = open(path, "rb").read()
     magic, dtype, ni, no, ns, nt, nins, nb, _r = struct.unpack_from("<8s8I", data, 0)
@@ -105,6 +130,17 @@ def test_table_compaction_is_exact():
     for _group, child, factor, parent in derived:
         k = float.fromhex(factor)
         np.testing.assert_array_equal(k*tables[int(parent)], tables[int(child)])
+#  the assembly body multiplies the same pairs (its annotations carry the factor's bits)
+#  (table numbers are those of the piece the kernel is lowered from)
+    from graph_framework_amd.backend import export_pieces
+    from oracle.gfir_to_c import parse
+    monkeypatch.delenv("GFHIP_ASM")
+    piece_tables = [t[2] for t in parse(export_pieces(path)[0]["gfir"])["tables"]]
+    multiplied = re.findall(r"; def c\d+_(\d+) = c\d+_(\d+) \* (\d+)", assembly)
+    assert len(multiplied) > 100
+    for child, parent, factor_bits in multiplied:
+        k = struct.unpack("<d", struct.pack("<Q", int(factor_bits)))[0]
+        np.testing.assert_array_equal(k*piece_tables[int(parent)], piece_tables[int(child)])
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
@@ -202,6 +238,7 @@ def test_emission_order_is_topological(lib, monkeypatch, schedule):
     import gfir_random
     from graph_framework_amd import generate_source
     monkeypatch.setenv("GFHIP_SCHEDULE", schedule)
+    monkeypatch.setenv("GFHIP_ASM", "0")                 # the compiled body's text (tests/test_asm_body.py replays the assembly one)
     source, _ = generate_source(os.path.join(WORKLOADS, "solver_kernel_f64.gfir"))
     assert _defined_before_use(source, "gfhip_solver_kernel") >= 3878
     blob, records = gfir_random.random_item(9, "f64", num_nodes=1500)
@@ -434,4 +471,5 @@ def test_split_items_compute_the_same_bits_on_the_oracle(lib, monkeypatch, workl
             assert np.array_equal(a, b, equal_nan=True)
     monkeypatch.delenv("GFHIP_SEGMENTS")
     monkeypatch.setenv("GFHIP_SEGMENT_NODES", "6000")
-    assert export_pieces(path) == []                                  # by default these items run as one kernel
+#  by default these items run as one kernel (the fp64 RK4 item as ONE piece whose body is assembly, plus the redo kernel)
+    assert len(export_pieces(path)) <= 1

@@ -129,3 +129,59 @@ def test_segments_with_a_redo_launch_on_the_division_edges(monkeypatch, tmp_path
                 assert _same(got, want), key
     assert context.flags() & 1                                       # lanes did leave the window
     context.close()
+
+
+ASSEMBLY_CASES = [  # seed, inputs, nodes, first register of the pool, waves per SIMD, LDS budget of the staged tables
+    (42, 6, 150, 64, 1, 65536),
+    (42, 6, 150, 224, 1, 65536),        # 16 register pairs: nearly every value goes through an LDS slot
+    (42, 6, 150, 224, 2, 0),            # ... and the tables are read from global memory
+    (46, 6, 300, 200, 1, 65536),
+    (47, 8, 500, 160, 1, 0),
+    (42, 8, 700, 64, 1, 65536),
+    (42, 8, 700, 64, 1, 0),
+]
+
+
+@pytest.mark.parametrize("seed,inputs,nodes,pool,waves,budget", ASSEMBLY_CASES,
+                         ids=["%d-nodes-pool-%d-waves-%d-lds-%d" % c[2:] for c in ASSEMBLY_CASES])
+def test_assembly_body_is_bit_exact(monkeypatch, tmp_path, seed, inputs, nodes, pool, waves, budget):
+    """csrc/asm_body.hpp (GFHIP_ASM=1): the body of a pass as gfx950 assembly with a register assignment of its own —
+    values sent to LDS slots and read back, table values loaded again (from LDS-staged and from global packs),
+    constants in an SGPR pool, counted waits — computes the bits of the oracle on random items, for separate launches
+    and fused passes; small register pools force the traffic through the slots that the RK4 item only sees at its
+    peaks."""
+    from graph_framework_amd import Context
+    from graph_framework_amd.backend import generate_piece_sources
+    monkeypatch.setenv("GFHIP_ASM", "1")
+    monkeypatch.setenv("GFHIP_ASM_MIN_NODES", "0")
+    monkeypatch.setenv("GFHIP_ASM_POOL_LO", str(pool))
+    monkeypatch.setenv("GFHIP_ASM_WAVES", str(waves))
+    monkeypatch.setenv("GFHIP_LDS_BUDGET", str(budget))
+    monkeypatch.setenv("GFHIP_CACHE_DIR", str(tmp_path))
+    outputs, setters, rays = 3, 3, 1777
+    blob, _ = gfir_random.random_item(seed, "f64", inputs, nodes, outputs, setters)
+    text = generate_piece_sources(blob)[0][0]
+    assert "v_fma_f64" in text and "v_rcp_f64" in text                  # the assembly body, not the compiled one
+    if pool > 64:
+        assert "ds_write_b64" in text and "ds_read_b64" in text
+    if budget == 0:
+        assert "global_load_dwordx2" in text
+    oracle_item = gfir.Item(blob)
+    rng = np.random.default_rng(2000 + seed)
+    initial = [rng.uniform(-1.0, 1.0, rays).astype(np.float64) for _ in range(inputs)]
+    context = Context(0)
+    in_keys = ["in%d" % i for i in range(inputs)]
+    out_keys = ["out%d" % i for i in range(outputs)]
+    kernel = context.add_kernel(blob, rays)
+    context.compile()
+    kernel.create_kernel_call(in_keys, out_keys, initial)
+    expected = [c.copy() for c in initial]
+    for launch_steps in (1, 1, 3):
+        expected_out, _ = oracle_item.run(expected, steps=launch_steps)
+        kernel.run(launch_steps)
+        context.wait()
+        assert context.flags() == 0
+        for key, want in zip(in_keys + out_keys, expected + expected_out):
+            got = context.copy_to_host(key, np.empty(rays, dtype=np.float64))
+            assert np.array_equal(got, want), (key, launch_steps, np.flatnonzero(got != want)[:5])
+    context.close()
