@@ -750,8 +750,10 @@ def run_rank(args):
                      "source_hash": "%016x" % info.source_hash,
                      "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE of profiles/traffic.json), null "
                                      "unless measured for this source hash and launch size",
-                     "note": "the kernel is FP64-VALU issue bound (one wave per SIMD, 4 cycles per vector "
-                             "instruction), not HBM bound: see DESIGN.md section 3"},
+                     "note": "the kernel is FP64-VALU issue bound, not HBM bound: ~5.9 k vector instructions per ray-step "
+                             "at ~4.2 cycles each, the vector unit busy 98 % of the time its waves are resident (two waves "
+                             "per SIMD, the pass as gfx950 assembly with a register assignment of its own: "
+                             "csrc/asm_body.hpp, DESIGN.md section 3)"},
         "fp64_vector": {"flops_per_ray_step": flops, "achieved_tflops": value/world*flops/1.0e12,
                         "peak_tflops": 78.6, "frac": value/world*flops/1.0e12/78.6,
                         "note": "per GPU; reference-DAG operation count, the roof that binds this kernel"},

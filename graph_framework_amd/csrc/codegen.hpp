@@ -71,6 +71,7 @@ struct lowered {
     uint32_t block_size = 256;
     size_t lds_bytes = 0;
     uint32_t park_slots = 0;            ///< LDS slots used for parked values
+    bool assembly = false;              ///< the pass is the assembly statement of asm_body.hpp
     bool has_converge = false;          ///< the module also holds `<name>_converge`
     bool has_max = false;               ///< the module also holds `<name>_max`
     uint32_t batch = 0;                 ///< the module also holds `<name>_batch`: up to this many passes per launch, each with its own max
@@ -944,6 +945,7 @@ inline lowered lower(const item &original, const codegen_options &opt = codegen_
     const std::string no_assembly;
     const bool as_assembly = assembly.ok && use_shared;
     if (as_assembly) resolved.waves_per_simd = opt.asm_waves;
+    out.assembly = as_assembly;
     kernel_writer writer{s, it, resolved, out, parent, factor, table_pack, table_column, plan, lds_used, park_offset, park_slots,
                          use_shared, after_division, piece, as_assembly ? assembly.statement : no_assembly};
     if (park_slots || as_assembly) s << "typedef __attribute__((address_space(3))) real park_t;\n";

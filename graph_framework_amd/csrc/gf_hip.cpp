@@ -610,6 +610,10 @@ static int build_module(gfhip_context *ctx, const gfhip::item &item, const gfhip
         resident = 1;
     }
     size_t cap = static_cast<size_t> (ctx->num_cus)*static_cast<size_t> (resident)*(resident == 1 ? 1 : 4);
+//  The assembly body (two workgroups resident per CU, VALU busy 98 % of the time its waves are resident): the finer the
+//  grid the better the CUs finish together — 2 per CU 1.90 ms per RK4 step at 1e7 rays, 8: 1.79, 16..48: 1.76, 64: 1.75,
+//  one workgroup per tile (153): 1.78 (profiles/r03_asm_grid.jsonl).
+    if (low.assembly) cap = static_cast<size_t> (ctx->num_cus)*64u;
     if (const char *env = std::getenv("GFHIP_GRID_PER_CU")) {
         cap = static_cast<size_t> (ctx->num_cus)*static_cast<size_t> (std::atoi(env) > 0 ? std::atoi(env) : 1);
     }
