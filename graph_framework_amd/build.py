@@ -49,7 +49,8 @@ def prebuild_kernel(gfir_path, force=False):
 
 #  Kernels of non-default lowerings that tests and bench.py use on the GPU box (each would otherwise cost the box a
 #  hipRTC build): (environment, workload file stem).
-VARIANTS = [({"GFHIP_DIVISION": "fast"}, "solver_kernel_f64"), ({"GFHIP_DIVISION": "fast"}, "loss_kernel_kx_f64")]
+VARIANTS = [({"GFHIP_DIVISION": "fast"}, "solver_kernel_f64"), ({"GFHIP_DIVISION": "fast"}, "loss_kernel_kx_f64"),
+            ({"GFHIP_ASM": "0"}, "solver_kernel_f64")]
 
 
 def variant_sources():

@@ -433,9 +433,51 @@ class asm_body_writer {
                 owner[static_cast<size_t> (p)] = id;
                 return true;
             }
+            const pack &pk = packs[g.pack];
+//  Two neighbouring columns of a global pack that are both wanted soon come with ONE 16-byte load into two adjacent
+//  free pairs (half the load instructions of a cell; with incoherent rays every load of a wave touches 64 cache lines).
+            if (!pk.in_lds && opt.asm_wide_loads) {
+                const uint32_t column = table_column[v.table];
+                int64_t partner = -1;
+                for (auto &kv : g.cells) {
+                    const value &w = values[static_cast<size_t> (kv.second)];
+                    if (kv.second == id || parent[w.table] >= 0 || w.reg >= 0) continue;
+                    const uint32_t other = table_column[w.table];
+                    if (other != column + 1 && other + 1 != column) continue;
+                    const size_t u = next_use(kv.second, position);
+                    if (u == never || u > position + 2*static_cast<size_t> (opt.asm_load_ahead) + 8) continue;
+                    partner = kv.second;
+                    break;
+                }
+                int first = -1;
+                if (partner >= 0) {
+                    for (size_t q = 0; q + 1 < owner.size(); q++) {
+                        if (owner[q] == -1 && owner[q + 1] == -1) { first = static_cast<int> (q); break; }
+                    }
+                }
+                if (first >= 0) {
+                    const bool id_is_low = table_column[values[static_cast<size_t> (partner)].table] > column;
+                    const int64_t low_id = id_is_low ? id : partner, high_id = id_is_low ? partner : id;
+                    const uint32_t low_column = table_column[values[static_cast<size_t> (low_id)].table];
+                    const uint32_t r = pool_lo + 2u*static_cast<uint32_t> (first);
+                    annotate("def " + value_name(low_id) + " " + value_name(high_id));
+                    line("global_load_dwordx4 v[" + std::to_string(r) + ":" + std::to_string(r + 3) + "], " + low_name(g.offset_pair) + ", %[pack" +
+                         std::to_string(g.pack) + "] offset:" + std::to_string(low_column*8u));
+                    const int64_t sequence = vm_issued++;
+                    result.loads++;
+                    const int64_t both[2] = {low_id, high_id};
+                    for (int k = 0; k < 2; k++) {
+                        value &loaded = values[static_cast<size_t> (both[k])];
+                        loaded.vm = sequence;
+                        loaded.reg = first + k;
+                        loaded.defined = true;
+                        owner[static_cast<size_t> (first + k)] = both[k];
+                    }
+                    return true;
+                }
+            }
             const int p = horizon ? take_pair(horizon) : need_pair();
             if (p < 0) return false;
-            const pack &pk = packs[g.pack];
             const std::string offset = std::to_string(table_column[v.table]*8u);
             annotate("def " + value_name(id));
             if (pk.in_lds) {

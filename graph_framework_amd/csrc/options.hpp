@@ -58,6 +58,7 @@ struct codegen_options {
                                         ///< assignment of its own (asm_body.hpp; two waves per SIMD, no AGPR copies; GFHIP_ASM=0: the compiled
                                         ///< body).  RK4 item, 1e7 rays: 1.814 ms per step against 2.043 ms
     uint32_t asm_waves = 2;             ///< ... waves per SIMD the kernel is built for: 2 leaves each workgroup 80 KB of LDS (40 slots) (GFHIP_ASM_WAVES)
+    bool asm_wide_loads = true;         ///< ... two neighbouring table columns wanted soon come with one 16-byte load (GFHIP_ASM_WIDE_LOADS=0)
     uint32_t asm_schedule_tries = 64;   ///< ... tie-breaks of the list schedule tried for the order that needs the fewest LDS slots (GFHIP_ASM_TRIES)
     uint32_t asm_min_nodes = 1000;      ///< ... (GFHIP_ASM_MIN_NODES)
     uint32_t asm_pool_lo = 40;          ///< first VGPR of the assembly body's pool; the compiler keeps v0..v(lo-1) (GFHIP_ASM_POOL_LO)
@@ -89,6 +90,7 @@ struct codegen_options {
         if (const char *e = std::getenv("GFHIP_PARK_PREFETCH")) o.park_prefetch = static_cast<uint32_t> (std::atoi(e));
         if (const char *e = std::getenv("GFHIP_ASM")) o.asm_body = std::string(e) != "0";
         if (const char *e = std::getenv("GFHIP_ASM_WAVES")) o.asm_waves = static_cast<uint32_t> (std::atoi(e)) == 2 ? 2 : 1;
+        if (const char *e = std::getenv("GFHIP_ASM_WIDE_LOADS")) o.asm_wide_loads = std::string(e) != "0";
         if (const char *e = std::getenv("GFHIP_ASM_TRIES")) o.asm_schedule_tries = static_cast<uint32_t> (std::atoi(e));
         if (const char *e = std::getenv("GFHIP_ASM_MIN_NODES")) o.asm_min_nodes = static_cast<uint32_t> (std::atoi(e));
         if (const char *e = std::getenv("GFHIP_ASM_POOL_LO")) o.asm_pool_lo = static_cast<uint32_t> (std::atoi(e));

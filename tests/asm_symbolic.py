@@ -203,6 +203,7 @@ def replay(blob, source):
     tracked = {"dmax": set(), "dmin": set(), "vmax": set()}
     outputs = []
     stats = {"instructions": 0, "spills": 0, "fills": 0, "loads": 0, "definitions": 0}
+    load_columns = {}               # group -> table value -> byte offset within the cell it is loaded from
 
     def fail(message, line):
         raise ReplayError("%s\n    in: %s" % (message, line))
@@ -365,6 +366,28 @@ def replay(blob, source):
             issued["vm"] += 1
             stats["loads"] += 1
             defined[name] = value
+            column = load_columns.setdefault(group, {}).setdefault(name, int(m.group(2)))
+            if column != int(m.group(2)):
+                fail("%s is loaded from two different columns" % name, line)
+        elif opcode == "global_load_dwordx4":
+#  two neighbouring columns of the cell in one load
+            address = read32(operands[1], line)
+            offset = int(re.fullmatch(r"%\[pack(\d+)\] offset:(\d+)", operands[2]).group(2))
+            lo = int(re.fullmatch(r"v\[(\d+):(\d+)\]", operands[0]).group(1))
+            names = re.fullmatch(r"def (c\d+_\d+) (c\d+_\d+)", note).groups()
+            for k, name in enumerate(names):
+                group = int(name[1:].split("_")[0])
+                if group not in groups or groups[group][0] != address[1]:
+                    fail("%s is loaded through a register that does not hold the cell offset of group %d" % (name, group), line)
+                value = expected.cells.setdefault(name, ex.mk("cell", *[int(x) for x in name[1:].split("_")]))
+                write_pair("v[%d:%d]" % (lo + 2*k, lo + 2*k + 1), value, line)
+                defined[name] = value
+                if load_columns.setdefault(group, {}).setdefault(name, offset + 8*k) != offset + 8*k:
+                    fail("%s is loaded from two different columns" % name, line)
+            for register in range(lo, lo + 4):
+                pending[register] = ("vm", issued["vm"])
+            issued["vm"] += 1
+            stats["loads"] += 1
         elif opcode == "ds_read_b64":
             lo = int(re.fullmatch(r"v\[(\d+):(\d+)\]", operands[0]).group(1))
             address_text, _, offset = operands[1].partition(" offset:")
@@ -403,7 +426,7 @@ def replay(blob, source):
         else:
             fail("opcode %s not understood" % opcode, line)
 
-        if note.startswith("def ") and opcode not in ("global_load_dwordx2", "ds_read_b64"):
+        if note.startswith("def ") and opcode not in ("global_load_dwordx2", "global_load_dwordx4", "ds_read_b64"):
             words = note.split()
             name = words[1]
             if name[0] == "g":

@@ -116,7 +116,12 @@ def test_bench_ray_newton_and_1000_steps_match_reference():
     assert solve.check_residual(0) == 7.7779641626949096e-13
 
 
-def test_solver_kernel_random_rays_vs_oracle():
+@pytest.mark.parametrize("body", ["assembly", "compiled"])
+def test_solver_kernel_random_rays_vs_oracle(monkeypatch, body):
+    """Both lowerings of the RK4 item: the assembly body (csrc/asm_body.hpp, the default) and the body hipcc compiles
+    (GFHIP_ASM=0: shared reciprocals, window checks, the `_ieee` function inside the kernel)."""
+    if body == "compiled":
+        monkeypatch.setenv("GFHIP_ASM", "0")
     s = random_plasma_state(257, seed=11)
     cols = [s[k] for k in STATE]
     new_cols, outs, info = _run_item("solver_kernel_f64.gfir", cols, 1, steps=5)
@@ -127,6 +132,7 @@ def test_solver_kernel_random_rays_vs_oracle():
         _assert_close(a, b)
     _assert_close(outs[0], ref_outs[0], rtol=1.0e-7)
     assert info.num_instructions == 3878
+    assert info.segments == (1 if body == "assembly" else 0) and (info.vgprs == 256 if body == "assembly" else info.vgprs > 400)
 
 
 def test_full_size_ensembles_through_size_independent_properties(golden_ref):
