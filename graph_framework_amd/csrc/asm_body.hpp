@@ -633,8 +633,12 @@ class asm_body_writer {
 //  The value of node i now lives in pair p.
     void define(const size_t i, const int p) {
         value &v = values[i];
-        v.reg = p;
         v.defined = true;
+        if (v.uses.empty()) {           // a node nobody reads (random items have a few): computed as the DAG says, kept nowhere
+            release_pair(p);
+            return;
+        }
+        v.reg = p;
         owner[static_cast<size_t> (p)] = static_cast<int64_t> (i);
     }
 
@@ -1039,12 +1043,33 @@ class asm_body_writer {
 ///  lifted; with two waves per SIMD a lane has 40 slots at most, the RK4 item needs 19 with its best order and 65
 ///  with the order schedule_for_pressure picks for the compiler.
 //------------------------------------------------------------------------------
-inline item schedule_for_assembly(const item &in, const codegen_options &opt) {
+///  `directories`: where the seed of the chosen order is remembered (`<hash of item and knobs>.order`, next to the code
+///  objects of the kernel cache): the search then runs once per item and machine, not once per process.
+inline item schedule_for_assembly(const item &in, const codegen_options &opt, const std::vector<std::string> &directories = {}) {
     if (in.code.size() > 20000 || !asm_body_writer::why_not(in, opt).empty()) return schedule_for_pressure(in);
+    const std::vector<uint8_t> bytes = in.serialize();
+    const uint64_t key = fnv1a(std::string(bytes.begin(), bytes.end()) + "|order|" + std::to_string(opt.asm_pool_lo) + "|" +
+                               std::to_string(opt.asm_load_ahead) + "|" + std::to_string(opt.asm_reload_ahead) + "|" +
+                               std::to_string(opt.asm_schedule_tries) + "|" + std::to_string(opt.asm_wide_loads) + "|" +
+                               std::to_string(opt.lds_budget) + "|" + std::to_string(opt.compact_tables) + "|" + std::to_string(opt.block_size));
+    char name[40];
+    std::snprintf(name, sizeof(name), "/%016llx.order", static_cast<unsigned long long> (key));
+    for (auto &directory : directories) {
+        if (FILE *f = std::fopen((directory + name).c_str(), "r")) {
+            unsigned int seed = 0;
+            const bool read = std::fscanf(f, "%u", &seed) == 1;
+            std::fclose(f);
+            if (read) return reorder(in, list_schedule(in, seed));
+        }
+    }
     const table_layout layout = layout_tables(in, opt);
     item best;
+    uint32_t best_seed = 0;
     size_t best_slots = ~static_cast<size_t> (0), best_traffic = 0;
-    for (uint32_t seed = 0; seed < std::max(1u, opt.asm_schedule_tries); seed++) {
+//  (the search costs tries x one writing of the statement: fewer tries for items far larger than the RK4 step)
+    const uint32_t tries = in.code.size() <= 5000 ? opt.asm_schedule_tries
+                         : std::max<uint32_t> (4u, static_cast<uint32_t> (opt.asm_schedule_tries*5000ull/in.code.size()));
+    for (uint32_t seed = 0; seed < std::max(1u, tries); seed++) {
         item candidate = reorder(in, list_schedule(in, seed));
         asm_body_writer writer(candidate, opt, layout.packs, layout.parent, layout.factor, layout.table_pack, layout.table_column,
                                opt.block_size, 1u << 20);
@@ -1055,9 +1080,18 @@ inline item schedule_for_assembly(const item &in, const codegen_options &opt) {
             best_slots = text.slots;
             best_traffic = traffic;
             best = std::move(candidate);
+            best_seed = seed;
         }
     }
-    return best.code.empty() ? schedule_for_pressure(in) : best;
+    if (best.code.empty()) return schedule_for_pressure(in);
+    for (auto &directory : directories) {
+        if (FILE *f = std::fopen((directory + name).c_str(), "w")) {
+            std::fprintf(f, "%u\n", best_seed);
+            std::fclose(f);
+            break;
+        }
+    }
+    return best;
 }
 
 ///  Whether the statement of `ordered` can be written within the LDS a workgroup has (lower() decides the same way).

@@ -310,7 +310,10 @@ static uint32_t plan_item(const gfhip::item &it, gfhip::lowered &whole, std::vec
     if (as_assembly) {
 //  ... if its values fit the register pool and the LDS slots in some emission order (lower() writes the statement of the
 //  piece below; here the same writer is asked whether it can).
-        ordered = gfhip::schedule_for_assembly(it, opt);
+        std::vector<std::string> directories;
+        if (const char *env = std::getenv("GFHIP_CACHE_DIR")) directories.push_back(env);
+        directories.push_back(library_directory() + "/kernel_cache");
+        ordered = gfhip::schedule_for_assembly(it, opt, directories);
         as_assembly = gfhip::assembly_fits(ordered, opt);
     }
     if (count < 2 && opt.segments != 1 && !as_assembly) {

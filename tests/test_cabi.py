@@ -82,7 +82,9 @@ def test_default_lowering_of_the_rk4_item_is_the_assembly_body(lib):
     assert len(re.findall(r"v_rcp_f64_e32 .*; def|v_fma_f64 .*; def q\d+", statement)) == 82      # one reciprocal per denominator
     assert len(re.findall(r"v_rcp_f64_e32", statement)) == 82 + 4              # ... and the four pow(x, 1.5)
     assert len(re.findall(r"v_rsq_f64_e32", statement)) == 11 + 4
-    assert 70 <= len(re.findall(r"global_load_dwordx2", statement)) <= 100     # 20 psi columns x 4 stages, a few loaded twice
+#  20 psi columns x 4 stages, neighbouring columns in one 16-byte load where both are wanted soon
+    narrow, wide = len(re.findall(r"global_load_dwordx2", statement)), len(re.findall(r"global_load_dwordx4", statement))
+    assert 80 <= narrow + 2*wide <= 100 and wide >= 30
     assert "v_accvgpr" not in statement and "scratch_" not in statement
     vector = len(re.findall(r'^\s*"v_', statement, re.M))
     assert vector < 6000                                                        # hipcc: ~6430 for the same pass
