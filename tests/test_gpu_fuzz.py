@@ -185,3 +185,40 @@ def test_assembly_body_is_bit_exact(monkeypatch, tmp_path, seed, inputs, nodes, 
             got = context.copy_to_host(key, np.empty(rays, dtype=np.float64))
             assert np.array_equal(got, want), (key, launch_steps, np.flatnonzero(got != want)[:5])
     context.close()
+
+
+def test_assembly_body_on_the_division_edges(monkeypatch, tmp_path):
+    """The window check of the assembly body (denominators and root arguments folded into dmax / dmin two at a time, the
+    index quotients into vmax) and its redo launch, where they matter: the division stress item on the operands of
+    tests/test_gpu_division.py (denominators of 2^+-600, zeros and infinities of both signs, infinite and overflowing
+    numerators).  Lanes outside the window skip their stores, line up in the redo list and are redone with the
+    compiler's division: every lane bit-identical to the oracle, over two passes."""
+    from graph_framework_amd import Context
+    from graph_framework_amd.backend import generate_piece_sources
+    from test_gpu_division import _operands, _same
+    monkeypatch.setenv("GFHIP_ASM_MIN_NODES", "0")
+    monkeypatch.setenv("GFHIP_CACHE_DIR", str(tmp_path))
+    blob = gfir_random.division_stress_item("f64")
+    assert "v_rcp_f64_e32" in generate_piece_sources(blob)[0][0]
+    oracle_item = gfir.Item(blob)
+    columns = _operands("f64", tiny_numerators=False)
+    repeat = 40000//columns[0].size + 1
+    columns = [np.tile(c, repeat)[:40000].copy() for c in columns]
+    rays = columns[0].size
+    context = Context(0)
+    kernel = context.add_kernel(blob, rays)
+    context.compile()
+    in_keys, out_keys = ["n0", "n1", "d0", "d1", "x"], ["q0", "q1", "q2", "q3", "mix"]
+    kernel.create_kernel_call(in_keys, out_keys, columns)
+    assert kernel.info().segments == 1 and kernel.info().vgprs <= 256
+    expected = [c.copy() for c in columns]
+    with np.errstate(all="ignore"):
+        for _ in range(2):
+            expected_out, _ = oracle_item.run(expected)
+            kernel.run(1)
+            context.wait()
+            for key, want in zip(in_keys + out_keys, expected + expected_out):
+                got = context.copy_to_host(key, np.empty(rays, dtype=np.float64))
+                assert _same(got, want), key
+    assert context.flags() & 1                                       # lanes did leave the window
+    context.close()
