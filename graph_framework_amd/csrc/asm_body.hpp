@@ -1062,6 +1062,9 @@ inline item schedule_for_assembly(const item &in, const codegen_options &opt, co
             if (read) return reorder(in, list_schedule(in, seed));
         }
     }
+    if (const char *forced = std::getenv("GFHIP_ASM_SEED")) {         // experiment: this tie-break, no search
+        return reorder(in, list_schedule(in, static_cast<uint32_t> (std::atoi(forced))));
+    }
     const table_layout layout = layout_tables(in, opt);
     item best;
     uint32_t best_seed = 0;
@@ -1076,6 +1079,10 @@ inline item schedule_for_assembly(const item &in, const codegen_options &opt, co
         const asm_body_text text = writer.write();
         if (!text.ok) continue;
         const size_t traffic = text.lds_reads + text.lds_writes;
+        if (std::getenv("GFHIP_ASM_REPORT")) {
+            std::fprintf(stderr, "  order %u of %s: %u slots, %zu LDS reads, %zu LDS writes, %zu loads, %zu waits\n", seed, in.name.c_str(), text.slots,
+                         text.lds_reads, text.lds_writes, text.loads, text.waits);
+        }
         if (text.slots < best_slots || (text.slots == best_slots && traffic < best_traffic)) {
             best_slots = text.slots;
             best_traffic = traffic;
