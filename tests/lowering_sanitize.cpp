@@ -43,6 +43,20 @@ static bool lower_bytes(const std::vector<char> &bytes, uint64_t &hash) {
                 hash ^= gfhip::lower(again, gfhip::codegen_options(), role).hash;
             }
         }
+//  The whole item as one piece whose pass is the assembly body (csrc/asm_body.hpp), whatever its size: the order search
+//  (three tie-breaks here), the writer with its register pool, LDS slots and look-ahead, a small pool as well.
+        for (const uint32_t pool : {40u, 200u}) {
+            gfhip::codegen_options assembly;
+            assembly.asm_min_nodes = 0;
+            assembly.asm_schedule_tries = 3;
+            assembly.asm_pool_lo = pool;
+            assembly.asm_waves = 1;
+            const gfhip::item chosen = gfhip::schedule_for_assembly(it, assembly);
+            gfhip::piece_info whole;
+            whole.role = gfhip::piece_role::last;
+            whole.scheduled = true;
+            hash ^= gfhip::lower(chosen, assembly, whole).hash;
+        }
         gfhip::piece_info redo;
         redo.role = gfhip::piece_role::redo;
         gfhip::codegen_options plain;
