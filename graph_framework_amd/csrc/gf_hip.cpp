@@ -389,6 +389,7 @@ extern "C" gfhip_kernel *gfhip_add_kernel(gfhip_context *ctx, const void *gfir, 
         chunk = chunk/1024*1024;
         if (chunk < 16384) chunk = 16384;
         k->chunk = num_rays < chunk ? num_rays : chunk;
+        if (slots == 0) k->chunk = num_rays;         // one piece (the assembly body): nothing is handed over, one walk over all rays
         k->handover.assign(slots, nullptr);
     }
     ctx->kernels.push_back(std::move(k));

@@ -14,6 +14,9 @@ python3 $R/bench.py --gpus 1 --backend nccl --force-collectives --no-extra --no-
 python3 $R/bench.py --workload korc --gpus 1 --backend nccl --force-collectives > $OUT/bench_korc_rccl_one_rank.json 2>> $OUT/bench_n1.err || exit 1
 python3 $R/bench.py --distribution cli --no-extra --no-cpu-baseline > $OUT/bench_cli_1e7.json 2>> $OUT/bench_n1.err || exit 1
 GFHIP_ASM=0 python3 $R/bench.py --no-extra --no-cpu-baseline > $OUT/bench_compiled_body.json 2>> $OUT/bench_n1.err || exit 1
+for rays in 50000000 100000000; do      # one GPU at the per-GPU shard sizes of C4
+    python3 $R/bench.py --rays-per-gpu $rays --steps 50 --warmup 5 --no-extra --no-cpu-baseline > $OUT/bench_rays_$rays.json 2>> $OUT/bench_n1.err || exit 1
+done
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --no-cpu-baseline --no-extra"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bench -- $B --steps 200 --warmup 10 > $OUT/stats_bench.log 2>&1 || exit 1
