@@ -506,7 +506,7 @@ struct kernel_writer {
               << "const unsigned int first, ";
         }
         if (piece.role == piece_role::redo) {
-            s << "unsigned char *__restrict__ flagged, const unsigned int *__restrict__ redo_list, const unsigned int *__restrict__ redo_count, ";
+            s << "unsigned char *__restrict__ flagged, const unsigned int *__restrict__ redo_list, unsigned int *__restrict__ redo_count, ";
         }
         if (which == entry::converge) {
             s << "const real tolerance,\n        const unsigned int max_iterations, unsigned int *__restrict__ iterations) {\n";
@@ -811,6 +811,18 @@ struct kernel_writer {
                 max_epilogue("lane_max" + std::to_string(b), "(reduce + " + std::to_string(b) + ")", "wave_max" + std::to_string(b));
                 s << "    }\n";
             }
+        }
+        if (piece.role == piece_role::redo) {
+//  The list is empty again for the next pass: the workgroup that finishes last — every workgroup has read the count by
+//  then — clears it and the arrival counter next to it (a memset per pass on the host's stream cost 5 us of every step).
+            s << "    __syncthreads();\n"
+              << "    if (threadIdx.x == 0u) {\n"
+              << "        __threadfence();\n"
+              << "        if (atomicAdd(redo_count + 1, 1u) == gridDim.x - 1u) {\n"
+              << "            redo_count[0] = 0u;\n"
+              << "            redo_count[1] = 0u;\n"
+              << "        }\n"
+              << "    }\n";
         }
         s << "}\n";
     }

@@ -672,8 +672,8 @@ static int build_kernel(gfhip_context *ctx, gfhip_kernel *k) {
             if (ctx->check(hipMalloc(reinterpret_cast<void **> (&k->flagged), rays), "hipMalloc(flagged)") ||
                 ctx->check(hipMemset(k->flagged, 0, rays), "hipMemset(flagged)") ||
                 ctx->check(hipMalloc(reinterpret_cast<void **> (&k->redo_list), rays*sizeof(unsigned int)), "hipMalloc(redo list)") ||
-                ctx->check(hipMalloc(reinterpret_cast<void **> (&k->redo_count), sizeof(unsigned int)), "hipMalloc(redo count)") ||
-                ctx->check(hipMemset(k->redo_count, 0, sizeof(unsigned int)), "hipMemset(redo count)")) {
+                ctx->check(hipMalloc(reinterpret_cast<void **> (&k->redo_count), 2*sizeof(unsigned int)), "hipMalloc(redo count)") ||
+                ctx->check(hipMemset(k->redo_count, 0, 2*sizeof(unsigned int)), "hipMemset(redo count)")) {
                 for (void *p : redo.packs) {
                     if (p) (void)hipFree(p);
                 }
@@ -883,7 +883,7 @@ static int launch_pieces(gfhip_kernel *k, const uint32_t steps) {
             GFHIP_TRY(ctx, hipModuleLaunchKernel(k->redo.function, 64, 1, 1, k->redo.low.block_size, 1, 1,
                                                  static_cast<unsigned int> (k->redo.low.lds_bytes), ctx->stream,
                                                  params.data(), nullptr), "hipModuleLaunchKernel(redo)");
-            GFHIP_TRY(ctx, hipMemsetAsync(k->redo_count, 0, sizeof(unsigned int), ctx->stream), "hipMemsetAsync(redo count)");
+//  (the redo kernel leaves the count — and its arrival counter, the second word — at zero)
         }
     }
     return 0;
