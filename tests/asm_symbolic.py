@@ -13,8 +13,6 @@ themselves (the GPU tests hold those against the oracle) and the layout of the t
 import re
 import struct
 
-import numpy as np
-
 from oracle.gfir_to_c import OPS, parse
 
 INLINE = {"0": 0.0, "0.5": 0.5, "-0.5": -0.5, "1.0": 1.0, "-1.0": -1.0, "2.0": 2.0, "-2.0": -2.0, "4.0": 4.0, "-4.0": -4.0}
