@@ -17,6 +17,7 @@ GFHIP_ASM=0 python3 $R/bench.py --no-extra --no-cpu-baseline > $OUT/bench_compil
 for rays in 50000000 100000000; do      # one GPU at the per-GPU shard sizes of C4
     python3 $R/bench.py --rays-per-gpu $rays --steps 50 --warmup 5 --no-extra --no-cpu-baseline > $OUT/bench_rays_$rays.json 2>> $OUT/bench_n1.err || exit 1
 done
+python3 $R/bench.py --rays-per-gpu 1000000 --steps 400 --warmup 20 --no-extra --no-cpu-baseline > $OUT/bench_rays_1000000.json 2>> $OUT/bench_n1.err || exit 1      # C2
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --no-cpu-baseline --no-extra"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bench -- $B --steps 200 --warmup 10 > $OUT/stats_bench.log 2>&1 || exit 1
