@@ -533,7 +533,9 @@ struct kernel_writer {
                 if (!out.packs[p].in_lds) continue;
                 const size_t count = out.packs[p].elements();
                 s << "    real *lds" << p << " = reinterpret_cast<real *> (lds_raw + " << offset << ");\n";
-                s << "    for (unsigned int k = threadIdx.x; k < " << count << "u; k += blockDim.x) lds" << p
+//  (the redo kernel runs after every pass and nearly always finds its list empty: it stages nothing then)
+                s << "    " << (piece.role == piece_role::redo ? "if (*redo_count != 0u) " : "")
+                  << "for (unsigned int k = threadIdx.x; k < " << count << "u; k += blockDim.x) lds" << p
                   << "[k] = pack" << p << "[k];\n";
                 offset += (count*esize + 15)/16*16;
             }
