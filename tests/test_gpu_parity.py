@@ -283,3 +283,21 @@ def test_incoherent_beam_500_steps():
     if lost.any():
         assert flagged_at is not None
     assert solve.residual().max() > 1.0                  # the beam does hold rays far off the dispersion surface
+
+
+def test_both_lowerings_of_the_rk4_item_agree_at_full_size():
+    """Where the oracle cannot follow (1e7 incoherent rays x 400 steps, 3e12 divisions): the assembly body with its redo
+    launch and the body hipcc compiles with its IEEE function are two independent lowerings of the same DAG — every
+    element of the state comes out with the same bits, the rays that blow up and the lanes that leave the division
+    window (status flags set) included.  `profiles/diag/asm/compare_bodies.py` runs each in a process of its own."""
+    import json
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "diag", "asm", "compare_bodies.py")
+    out = subprocess.run([sys.executable, script, "10000000", "400"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    report = json.loads(out.stdout.strip().splitlines()[-1])
+    assert report["bit_identical"] and not any(report["elements_that_differ"].values())
+    assert report["assembly"]["segments"] == 1 and report["compiled"]["segments"] == 0
+    assert report["assembly"]["flags"] == report["compiled"]["flags"] != 0          # lanes did take the IEEE path
+    assert report["assembly"]["non_finite_rays"] == report["compiled"]["non_finite_rays"]
