@@ -880,7 +880,9 @@ static int launch_pieces(gfhip_kernel *k, const uint32_t steps) {
             params.push_back(&k->redo_list);
             params.push_back(&k->redo_count);
             params.push_back(&one);
-            GFHIP_TRY(ctx, hipModuleLaunchKernel(k->redo.function, 64, 1, 1, k->redo.low.block_size, 1, 1,
+//  One workgroup per CU: an empty list costs the launch either way (5 us), a long one (the O-mode step on the CLI beam
+//  sends a third of its lanes here) is walked by the whole chip.
+            GFHIP_TRY(ctx, hipModuleLaunchKernel(k->redo.function, ctx->num_cus, 1, 1, k->redo.low.block_size, 1, 1,
                                                  static_cast<unsigned int> (k->redo.low.lds_bytes), ctx->stream,
                                                  params.data(), nullptr), "hipModuleLaunchKernel(redo)");
 //  (the redo kernel leaves the count — and its arrival counter, the second word — at zero)
