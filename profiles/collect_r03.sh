@@ -1,5 +1,7 @@
 #!/bin/bash
-# Round-3 evidence, one gpurun call:   gpurun --timeout 1200 -- 'bash profiles/collect_r03.sh'
+# Round-3 evidence BEFORE the assembly body became the default lowering of the RK4 item (profiles/r03_*); to reproduce it
+# now, export GFHIP_ASM=0 first.  The final state of the round is collected by profiles/collect_r03b.sh (profiles/r03b_*).
+# One gpurun call:   gpurun --timeout 1200 -- 'bash profiles/collect_r03.sh'
 # Everything lands in gpurun_out/r03/; profiles/summarize.py turns it into the files kept in profiles/.
 # Counters are collected in their own passes (never together with --stats or trace domains); the
 # program itself follows `--` (python3 ...), environment variables are exported beforehand, the profiler runs from /tmp.
