@@ -32,8 +32,11 @@
 ///
 ///  Pieces: options.hpp (knobs, cache hash), schedule.hpp (emission order),
 ///  tables.hpp (compaction, packs, LDS staging), parking.hpp (values that wait
-///  in LDS), prelude.hpp (device helpers: division, window checks, pow), and
-///  lower() below, which writes the kernel text.
+///  in LDS), prelude.hpp (device helpers: division, window checks, pow),
+///  segments.hpp (items cut into several kernels, the redo launch), asm_body.hpp
+///  (the pass of a large fp64 item as gfx950 assembly with a register assignment
+///  of its own: the RK4 step's default), and lower() below, which writes the
+///  kernel text.
 //------------------------------------------------------------------------------
 #ifndef gfhip_codegen_hpp
 #define gfhip_codegen_hpp
