@@ -197,6 +197,26 @@ def dag_flops(path):
     return flops
 
 
+def vector_issue(gfir_path, rays, kernel_ms, num_cus=256):
+    """The roof that binds the RK4 kernel: vector instructions of one pass of its assembly body (counted in the kernel
+    text the lowering writes) and the time a SIMD spends per instruction of a wave, next to what a microbenchmark of
+    nothing but fp64 vector instructions gets from a SIMD of this chip (profiles/diag/fp64_issue/)."""
+    try:
+        from graph_framework_amd.backend import generate_piece_sources
+        text = generate_piece_sources(gfir_path)[0][0]
+        start = text.index("asm volatile(\n", text.index("float dmax"))
+        statement = text[start:text.index("                : [", start)]
+    except (ValueError, IndexError):
+        return None                                  # the compiled body (GFHIP_ASM=0): hipcc's count is not in the text
+    instructions = sum(1 for line in statement.split("\n") if line.lstrip().startswith('"v_'))
+    tiles_per_simd = rays/64.0/(4.0*num_cus)
+    return {"vector_instructions_per_pass": instructions,
+            "ns_per_instruction": 1.0e6*kernel_ms/(tiles_per_simd*instructions) if kernel_ms > 0 and instructions else None,
+            "microbenchmark_ns_per_instruction": [1.83, 2.43],
+            "note": "ns a SIMD spends per vector instruction of a pass (two waves resident, every SIMD of 256 CUs busy); the "
+                    "microbenchmark range is dependent mul/add chains at four waves to one dependent fma chain at one wave"}
+
+
 def measured_traffic(kernel_name, source_hash, rays):
     """HBM bytes per launch from the committed PMC passes (profiles/traffic.json, written by
     profiles/summarize.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this command) —
@@ -754,6 +774,7 @@ def run_rank(args):
                              "at ~4.2 cycles each, the vector unit busy 98 % of the time its waves are resident (two waves "
                              "per SIMD, the pass as gfx950 assembly with a register assignment of its own: "
                              "csrc/asm_body.hpp, DESIGN.md section 3)"},
+        "vector_issue": vector_issue(workload("solver_kernel"), n_local, kernel_ms),
         "fp64_vector": {"flops_per_ray_step": flops, "achieved_tflops": value/world*flops/1.0e12,
                         "peak_tflops": 78.6, "frac": value/world*flops/1.0e12/78.6,
                         "note": "per GPU; reference-DAG operation count, the roof that binds this kernel"},
