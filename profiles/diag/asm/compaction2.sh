@@ -1,3 +1,6 @@
+#!/bin/bash
+#  Follow-up of compaction.sh: the uncompacted tables with no LDS staging and with coarser grids, and the compacted ones
+#  without staging (default bench line of each, two rounds, one box).
 mkdir -p /tmp/asm_cache
 run() { label=$1; shift; env GFHIP_CACHE_DIR=/tmp/asm_cache "$@" python bench.py --no-extra --no-cpu-baseline --steps 100 2>/dev/null | python -c "
 import sys, json
