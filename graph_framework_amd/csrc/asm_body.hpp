@@ -1047,6 +1047,9 @@ class asm_body_writer {
 ///  objects of the kernel cache): the search then runs once per item and machine, not once per process.
 inline item schedule_for_assembly(const item &in, const codegen_options &opt, const std::vector<std::string> &directories = {}) {
     if (in.code.size() > 20000 || !asm_body_writer::why_not(in, opt).empty()) return schedule_for_pressure(in);
+    if (const char *forced = std::getenv("GFHIP_ASM_SEED")) {         // experiment (profiles/diag/asm/seeds.sh): this tie-break, no search
+        return reorder(in, list_schedule(in, static_cast<uint32_t> (std::atoi(forced))));
+    }
     const std::vector<uint8_t> bytes = in.serialize();
     const uint64_t key = fnv1a(std::string(bytes.begin(), bytes.end()) + "|order|" + std::to_string(opt.asm_pool_lo) + "|" +
                                std::to_string(opt.asm_load_ahead) + "|" + std::to_string(opt.asm_reload_ahead) + "|" +
@@ -1061,9 +1064,6 @@ inline item schedule_for_assembly(const item &in, const codegen_options &opt, co
             std::fclose(f);
             if (read) return reorder(in, list_schedule(in, seed));
         }
-    }
-    if (const char *forced = std::getenv("GFHIP_ASM_SEED")) {         // experiment: this tie-break, no search
-        return reorder(in, list_schedule(in, static_cast<uint32_t> (std::atoi(forced))));
     }
     const table_layout layout = layout_tables(in, opt);
     item best;
