@@ -21,7 +21,10 @@ def lowered(blob_path, environment):
               "from graph_framework_amd.backend import generate_piece_sources, export_pieces\n"
               "blob = open(%r, 'rb').read()\n"
               "print(json.dumps([base64.b64encode(export_pieces(blob)[0]['gfir']).decode(), generate_piece_sources(blob)[0][0]]))" % (ROOT, blob_path))
-    env = dict(os.environ, GFHIP_ASM="1", **environment)
+#  (what the order search remembers goes to a scratch directory, not into the in-tree kernel cache)
+    import tempfile
+    scratch = tempfile.mkdtemp(prefix="gfhip_orders_")
+    env = dict(os.environ, GFHIP_ASM="1", **dict(dict(GFHIP_CACHE_DIR=scratch), **environment))
     out = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, check=True)
     import base64
     import json
@@ -76,3 +79,21 @@ def test_a_corrupted_statement_is_caught():
     assert swapped != lines[target]
     with pytest.raises(asm_symbolic.ReplayError):
         asm_symbolic.replay(piece, "\n".join(lines[:target] + [swapped] + lines[target + 1:]))
+
+
+def test_the_chosen_order_is_remembered_and_reproducible(tmp_path):
+    """schedule_for_assembly searches 64 tie-breaks once and leaves `<hash>.order` next to the code objects; a second
+    lowering reads it and writes the same kernel text — and so does a lowering that cannot find it (the search is
+    deterministic), which is what the GPU box relies on when the cache directory does not travel."""
+    workload = os.path.join(WORKLOADS, "solver_kernel_f64.gfir")
+    first_cache, second_cache = tmp_path/"a", tmp_path/"b"
+    first_cache.mkdir()
+    second_cache.mkdir()
+#  (eight tie-breaks instead of 64: a key of its own, nothing remembered for it in the in-tree kernel cache)
+    knobs = dict(GFHIP_ASM_TRIES="8")
+    _, first = lowered(workload, dict(knobs, GFHIP_CACHE_DIR=str(first_cache)))
+    remembered = [name for name in os.listdir(first_cache) if name.endswith(".order")]
+    assert len(remembered) == 1 and int(open(first_cache/remembered[0]).read()) >= 0
+    _, again = lowered(workload, dict(knobs, GFHIP_CACHE_DIR=str(first_cache)))
+    _, fresh = lowered(workload, dict(knobs, GFHIP_CACHE_DIR=str(second_cache)))
+    assert again == first and fresh == first
