@@ -84,8 +84,9 @@ def prebuild_workloads(force=False):
         built = list(pool.map(lambda piece: compile_source(piece[0], piece[1], force), texts))
 #  Drop code objects of earlier lowerings (the cache key is the source hash).
     keep = {os.path.splitext(b)[0] for b in built}
+#  (`<hash>.order` files stay: the emission order the assembly body's search chose for an item, asm_body.hpp)
     for stale in glob.glob(os.path.join(_lib.CACHE_DIR, "*")):
-        if os.path.splitext(stale)[0] not in keep:
+        if os.path.splitext(stale)[0] not in keep and not stale.endswith(".order"):
             os.remove(stale)
     return built
 
