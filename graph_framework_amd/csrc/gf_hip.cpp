@@ -96,7 +96,9 @@ struct gfhip_context {
     std::vector<std::unique_ptr<gfhip_kernel>> kernels;
     std::string error;
     unsigned long long *device_scalar = nullptr;
-    unsigned long long *host_scalar = nullptr;     // pinned
+    unsigned long long *host_scalar = nullptr;     // pinned, 8 words
+    gfhip_kernel *running_ahead = nullptr;         // the kernel whose last batch ran passes the caller has not asked for yet
+    gfhip_kernel *max_streak = nullptr;            // the kernel the last entry point was gfhip_run_max of
     unsigned int *device_flags = nullptr;          // bit 0: a lane redid a pass with the compiler's division
     gfhip::converge_state *device_converge = nullptr;
     gfhip::converge_state *host_converge = nullptr;   // pinned
@@ -144,6 +146,10 @@ struct gfhip_kernel {
     hipFunction_t max_function = nullptr;
     hipFunction_t batch_function = nullptr;         // `<name>_batch`: several passes per launch, one max per pass
     std::vector<void *> undo;                      // per setter: the target's values at the beginning of the last batch
+//  gfhip_run_max called in a row (the reference's converge_item::run, workflow.hpp:179-205, through hip_context's
+//  create_max_call): passes of the last `<name>_batch` launch that ran ahead of the caller, their maxes waiting here.
+    std::vector<double> ahead;
+    unsigned int ahead_taken = 0;
     bool built = false;
     bool from_cache = false;
     std::vector<void *> pack_device;
@@ -225,7 +231,7 @@ extern "C" gfhip_context *gfhip_create_context(int index, void *stream) {
         hipMemset(ctx->device_flags, 0, sizeof(unsigned int)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **> (&ctx->device_scalar), 8*sizeof(unsigned long long)) != hipSuccess ||     // one per pass of a batch
         hipMemset(ctx->device_scalar, 0, 8*sizeof(unsigned long long)) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void **> (&ctx->host_scalar), sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void **> (&ctx->host_scalar), 8*sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **> (&ctx->device_converge), sizeof(gfhip::converge_state)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **> (&ctx->host_converge), sizeof(gfhip::converge_state), hipHostMallocDefault) != hipSuccess) {
         creation_error = "cannot allocate reduction scalars";
@@ -726,6 +732,10 @@ static int build_kernel(gfhip_context *ctx, gfhip_kernel *k) {
     return 0;
 }
 
+//  Passes that ran ahead of a caller iterating on gfhip_run_max are taken back before anything else looks at the state
+//  (defined with the batch launches below).
+static int settle(gfhip_context *ctx);
+
 extern "C" int gfhip_compile(gfhip_context *ctx) {
     if (!ctx) return 1;
     GFHIP_TRY(ctx, hipSetDevice(ctx->device), "hipSetDevice");
@@ -776,6 +786,7 @@ extern "C" int gfhip_create_kernel_call(gfhip_kernel *k, const uint64_t *input_k
     if (!k) return 1;
     gfhip_context *ctx = k->ctx;
     GFHIP_TRY(ctx, hipSetDevice(ctx->device), "hipSetDevice");
+    if (settle(ctx)) return 1;
     const size_t ni = k->item.symbols.size(), no = k->item.outputs.size();
     k->input_keys.assign(input_keys, input_keys + ni);
     k->output_keys.assign(output_keys, output_keys + no);
@@ -964,6 +975,7 @@ static int launch(gfhip_kernel *k, const uint32_t steps, unsigned long long *red
 extern "C" int gfhip_run(gfhip_kernel *k, uint32_t steps) {
     if (!k) return 1;
     GFHIP_TRY(k->ctx, hipSetDevice(k->ctx->device), "hipSetDevice");
+    if (settle(k->ctx)) return 1;
     return launch(k, steps);
 }
 
@@ -1007,6 +1019,7 @@ extern "C" int gfhip_run_max_complex(gfhip_kernel *k, double *value) {
         value[1] = 0.0;
         return gfhip_run_max(k, value);
     }
+    if (settle(ctx)) return 1;
     if (launch(k, 1)) return 1;
     value[0] = value[1] = 0.0;
     if (k->num_rays == 0) return 0;
@@ -1030,6 +1043,7 @@ extern "C" int gfhip_run_max_complex(gfhip_kernel *k, double *value) {
 extern "C" int gfhip_reduce_max(gfhip_context *ctx, uint64_t key, double *value) {
     if (!ctx || !value) return 1;
     GFHIP_TRY(ctx, hipSetDevice(ctx->device), "hipSetDevice");
+    if (settle(ctx)) return 1;
     auto found = ctx->buffers.find(key);
     if (found == ctx->buffers.end()) return ctx->fail("unknown buffer key");
     const buffer &b = found->second;
@@ -1065,12 +1079,17 @@ extern "C" int gfhip_reduce_max(gfhip_context *ctx, uint64_t key, double *value)
     return 0;
 }
 
+static int run_max_ahead(gfhip_kernel *k, double *max_value, bool &answered);
+
 extern "C" int gfhip_run_max(gfhip_kernel *k, double *max_value) {
     if (!k) return 1;
     gfhip_context *ctx = k->ctx;
     GFHIP_TRY(ctx, hipSetDevice(ctx->device), "hipSetDevice");
     if (k->output_keys.empty()) return ctx->fail("converge item has no output to reduce");
     if (k->item.is_complex()) return ctx->fail("complex item: use gfhip_run_max_complex");
+    bool answered = false;
+    if (run_max_ahead(k, max_value, answered)) return 1;
+    if (answered) return 0;
     GFHIP_TRY(ctx, hipMemsetAsync(ctx->device_scalar, 0, sizeof(unsigned long long), ctx->stream), "hipMemsetAsync");
     if (enqueue_pass_with_max(k, nullptr)) return 1;
     GFHIP_TRY(ctx, hipMemcpyAsync(ctx->host_scalar, ctx->device_scalar, sizeof(unsigned long long),
@@ -1230,6 +1249,74 @@ static int launch_batch(gfhip_kernel *k, const unsigned int passes, const unsign
     return 0;
 }
 
+//  gfhip_run_max called again and again with nothing in between is the reference's converge loop seen from below
+//  (workflow.hpp:179-205: the host tests every max; hip_context's create_max_call forwards each call here).  From the
+//  second call of such a streak on, a `<name>_batch` launch runs the pass that is asked for AND the next ones, each with
+//  its own max; the following calls are answered from those maxes without a launch or a synchronisation.  Whatever
+//  entry point comes next (settle) takes back the passes nobody asked for: the state of the beginning of the batch is
+//  in the undo arrays, the passes that were asked for run again.  25 passes of the benchmark's Newton solve: 10 launches
+//  and host synchronisations instead of 25.  GFHIP_RUN_AHEAD=0 turns it off.
+static int settle(gfhip_context *ctx) {
+    ctx->max_streak = nullptr;
+    gfhip_kernel *k = ctx->running_ahead;
+    if (!k) return 0;
+    ctx->running_ahead = nullptr;
+    const unsigned int asked = k->ahead_taken, ran = static_cast<unsigned int> (k->ahead.size());
+    k->ahead.clear();
+    k->ahead_taken = 0;
+    if (asked == ran) return 0;
+    const size_t esize = k->item.element_size();
+    for (size_t s = 0; s < k->item.setters.size(); s++) {
+        void *target = ctx->buffers[k->input_keys[k->item.setters[s].input]].pointer;
+        GFHIP_TRY(ctx, hipMemcpyAsync(target, k->undo[s], k->num_rays*esize, hipMemcpyDeviceToDevice, ctx->stream),
+                  "hipMemcpyAsync(undo)");
+    }
+    return launch_batch(k, asked, nullptr);
+}
+
+static int run_max_ahead(gfhip_kernel *k, double *max_value, bool &answered) {
+    gfhip_context *ctx = k->ctx;
+    answered = false;
+    static const bool enabled = !(std::getenv("GFHIP_RUN_AHEAD") && std::string(std::getenv("GFHIP_RUN_AHEAD")) == "0");
+    if (ctx->running_ahead == k && k->ahead_taken < k->ahead.size()) {
+        *max_value = k->ahead[k->ahead_taken++];
+        answered = true;
+        return 0;
+    }
+    const bool streak = ctx->max_streak == k;
+    if (ctx->running_ahead == k) {
+//  every pass of the last batch was asked for: nothing to take back
+        ctx->running_ahead = nullptr;
+        k->ahead.clear();
+        k->ahead_taken = 0;
+    } else if (settle(ctx)) {
+        return 1;
+    }
+    ctx->max_streak = k;
+    if (!enabled || !streak || !k->batch_function || k->num_rays == 0 || k->low.batch < 2) return 0;
+    if (k->undo.empty()) {
+        const size_t esize = k->item.element_size();
+        for (size_t s = 0; s < k->item.setters.size(); s++) {
+            void *p = nullptr;
+            GFHIP_TRY(ctx, hipMalloc(&p, k->num_rays*esize), "hipMalloc(undo)");
+            k->undo.push_back(p);
+        }
+    }
+    const unsigned int batch = std::min(k->low.batch, 8u);
+    GFHIP_TRY(ctx, hipMemsetAsync(ctx->device_scalar, 0, 8*sizeof(unsigned long long), ctx->stream), "hipMemsetAsync");
+    if (launch_batch(k, batch, nullptr)) return 1;
+    GFHIP_TRY(ctx, hipMemcpyAsync(ctx->host_scalar, ctx->device_scalar, batch*sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                                  ctx->stream), "hipMemcpyAsync");
+    GFHIP_TRY(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
+    k->ahead.clear();
+    for (unsigned int b = 0; b < batch; b++) k->ahead.push_back(decode_ordered(ctx->host_scalar[b], k->item.dtype == GFIR_F64));
+    k->ahead_taken = 1;
+    ctx->running_ahead = k;
+    *max_value = k->ahead[0];
+    answered = true;
+    return 0;
+}
+
 //  The converge loop with several passes per launch (`<name>_batch`, codegen.hpp).  A pass of this loop
 //  only feeds the next pass of the same ray and the max the loop's test looks at, so a launch may run a
 //  few passes on state kept in registers — each pass leaving its own max — and the test (on the device,
@@ -1312,6 +1399,7 @@ extern "C" int gfhip_converge(gfhip_kernel *k, double tolerance, size_t max_iter
     gfhip_context *ctx = k->ctx;
     GFHIP_TRY(ctx, hipSetDevice(ctx->device), "hipSetDevice");
     if (k->output_keys.empty()) return ctx->fail("converge item has no output to reduce");
+    if (settle(ctx)) return 1;
     if (!k->built) return ctx->fail("kernel has not been compiled (gfhip_compile)");
     if (!k->bound) return ctx->fail("kernel arguments are not bound (gfhip_create_kernel_call)");
     size_t used = 0;
@@ -1345,6 +1433,7 @@ extern "C" int gfhip_converge_per_ray(gfhip_kernel *k, double tolerance, size_t 
     if (!k) return 1;
     gfhip_context *ctx = k->ctx;
     GFHIP_TRY(ctx, hipSetDevice(ctx->device), "hipSetDevice");
+    if (settle(ctx)) return 1;
     if (!k->built) return ctx->fail("kernel has not been compiled (gfhip_compile)");
     if (!k->converge_function) return ctx->fail("item has no setter/output to converge on");
     if (!k->bound) return ctx->fail("kernel arguments are not bound (gfhip_create_kernel_call)");
@@ -1396,6 +1485,7 @@ extern "C" int gfhip_converge_per_ray(gfhip_kernel *k, double tolerance, size_t 
 extern "C" int gfhip_wait(gfhip_context *ctx) {
     if (!ctx) return 1;
     GFHIP_TRY(ctx, hipSetDevice(ctx->device), "hipSetDevice");
+    if (settle(ctx)) return 1;
 //  Host mirrors handed out by gfhip_get_host_buffer hold the device contents as of this drain:
 //  all copies are queued behind the kernels, then ONE synchronisation.
     for (auto &kv : ctx->buffers) {
@@ -1412,6 +1502,7 @@ extern "C" int gfhip_wait(gfhip_context *ctx) {
 extern "C" int gfhip_get_flags(gfhip_context *ctx, unsigned int *flags) {
     if (!ctx || !flags) return 1;
     GFHIP_TRY(ctx, hipSetDevice(ctx->device), "hipSetDevice");
+    if (settle(ctx)) return 1;
     GFHIP_TRY(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
     GFHIP_TRY(ctx, hipMemcpy(flags, ctx->device_flags, sizeof(unsigned int), hipMemcpyDeviceToHost), "hipMemcpy(flags)");
     return 0;
@@ -1431,6 +1522,7 @@ extern "C" int gfhip_copy_to_device(gfhip_context *ctx, uint64_t key, const void
     buffer *b = find_buffer(ctx, key);
     if (!b) return 1;
     GFHIP_TRY(ctx, hipSetDevice(ctx->device), "hipSetDevice");
+    if (settle(ctx)) return 1;
     GFHIP_TRY(ctx, hipMemcpyAsync(b->pointer, host, b->count*element_bytes(b->dtype),
                                   hipMemcpyHostToDevice, ctx->stream), "hipMemcpyAsync(H2D)");
     GFHIP_TRY(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
@@ -1442,6 +1534,7 @@ extern "C" int gfhip_copy_to_host(gfhip_context *ctx, uint64_t key, void *host) 
     buffer *b = find_buffer(ctx, key);
     if (!b) return 1;
     GFHIP_TRY(ctx, hipSetDevice(ctx->device), "hipSetDevice");
+    if (settle(ctx)) return 1;
     GFHIP_TRY(ctx, hipMemcpyAsync(host, b->pointer, b->count*element_bytes(b->dtype),
                                   hipMemcpyDeviceToHost, ctx->stream), "hipMemcpyAsync(D2H)");
     GFHIP_TRY(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
@@ -1454,6 +1547,7 @@ extern "C" int gfhip_read_element(gfhip_context *ctx, uint64_t key, size_t index
     if (!b) return 1;
     if (index >= b->count) return ctx->fail("index out of range");
     GFHIP_TRY(ctx, hipSetDevice(ctx->device), "hipSetDevice");
+    if (settle(ctx)) return 1;
     GFHIP_TRY(ctx, hipStreamSynchronize(ctx->stream), "hipStreamSynchronize");
     const size_t esize = element_bytes(b->dtype);
     GFHIP_TRY(ctx, hipMemcpy(element, static_cast<char *> (b->pointer) + index*esize, esize, hipMemcpyDeviceToHost), "hipMemcpy");
@@ -1480,6 +1574,7 @@ extern "C" int gfhip_set_random_state(gfhip_kernel *k, uint64_t key, const void 
     const size_t needed = 1024*2500;
     if (!states || bytes < needed) return ctx->fail("a random state of 1024 MT19937 states (2500 bytes each) is required");
     GFHIP_TRY(ctx, hipSetDevice(ctx->device), "hipSetDevice");
+    if (settle(ctx)) return 1;
     auto found = ctx->random_states.find(key);
     if (found == ctx->random_states.end()) {
         void *device = nullptr;
@@ -1499,6 +1594,7 @@ extern "C" void *gfhip_get_buffer(gfhip_context *ctx, uint64_t key, size_t *coun
     if (!ctx) return nullptr;
     buffer *b = find_buffer(ctx, key);
     if (!b) return nullptr;
+    if (hipSetDevice(ctx->device) != hipSuccess || settle(ctx)) return nullptr;      // the caller is about to look at the device buffer
     if (count) *count = b->count;
     return b->pointer;
 }
@@ -1523,7 +1619,7 @@ extern "C" void *gfhip_get_host_buffer(gfhip_context *ctx, uint64_t key, size_t 
     if (!ctx) return nullptr;
     buffer *b = find_buffer(ctx, key);
     if (!b) return nullptr;
-    if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+    if (hipSetDevice(ctx->device) != hipSuccess || settle(ctx)) return nullptr;
     const size_t bytes = b->count*element_bytes(b->dtype);
     if (!b->mirror) {
         if (ctx->check(hipHostMalloc(&b->mirror, bytes ? bytes : 8, hipHostMallocDefault), "hipHostMalloc(mirror)")) {
@@ -1541,6 +1637,7 @@ extern "C" void *gfhip_get_host_buffer(gfhip_context *ctx, uint64_t key, size_t 
 
 extern "C" int gfhip_set_buffer(gfhip_context *ctx, uint64_t key, void *device_pointer, size_t count, uint32_t dtype) {
     if (!ctx) return 1;
+    if (settle(ctx)) return 1;
     if (!device_pointer && count) return ctx->fail("null device pointer");
     if (dtype > GFIR_C64) return ctx->fail("bad dtype");
     auto found = ctx->buffers.find(key);

@@ -95,7 +95,16 @@ int gfhip_run(gfhip_kernel *kernel, uint32_t steps);
  * return the scalar.  Items of up to 1500 nodes reduce inside the launch
  * (`<name>_max`: wave shuffle + one atomic per workgroup); larger ones run the
  * separate reduction kernel over the output buffer.  Replaces
- * create_max_call(arg, run)  (cuda_context.hpp:540-576, cpu_context.hpp:306-322). */
+ * create_max_call(arg, run)  (cuda_context.hpp:540-576, cpu_context.hpp:306-322).
+ * Called again and again with no other entry point in between — which is what the
+ * reference's converge_item::run (workflow.hpp:179-205) does through that closure — it
+ * runs ahead: from the second call of the streak on, one `<name>_batch` launch runs
+ * the asked pass and the next ones, each with its own max, the following calls are
+ * answered from those without a launch or a synchronisation, and the next entry point
+ * of any kind first takes back the passes nobody asked for (state of the beginning of
+ * the batch restored, the asked passes run again).  Same values, same state, fewer
+ * launches (10 instead of 25 for the benchmark's Newton solve); GFHIP_RUN_AHEAD=0
+ * keeps one launch per call. */
 int gfhip_run_max(gfhip_kernel *kernel, double *max_value);
 
 /* The same for items of a complex type (enum gfir_dtype GFIR_C32 / GFIR_C64): value[0] + i value[1] =
