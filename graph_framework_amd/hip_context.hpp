@@ -346,7 +346,9 @@ namespace gpu {
 //  The contract (jit.hpp:274-277; cuda_context.hpp:540-576, cpu_context.hpp:306-322): run `run`,
 //  then reduce the buffer that holds `argument`.  `run` is normally the closure the preceding
 //  create_kernel_call returned (workflow.hpp:172): when it is, and `argument` is the LAST output
-//  that kernel stores, the max is folded into the kernel's own launch (gfhip_run_max).  In every
+//  that kernel stores, the max is folded into the kernel's own launch (gfhip_run_max — which, called in a row as
+//  workflow.hpp:179-205 calls this closure, runs ahead: a batch of passes per launch, each with its own max, the
+//  passes nobody asked for taken back by the next entry point; include/gf_hip.h).  In every
 //  other case — a foreign `run`, an argument that is a variable, that a setter stores or that is
 //  not the last output — `run` runs as given and the buffer holding `argument` is reduced.
             const kernel_call *call = run.template target<kernel_call> ();
